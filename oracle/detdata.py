@@ -1,0 +1,99 @@
+"""Deterministic, platform-independent test data.  TEST INFRASTRUCTURE ONLY.
+
+Golden vectors must be reproducible on the GPU box, where neither /root/reference nor the
+RNG stream of the torch build that generated them is guaranteed.  Weights and inputs are
+therefore derived from a counter-based hash (splitmix64 over `crc32(name) + index`)
+implemented with numpy integer arithmetic only: the same bits everywhere.
+
+`det_state_dict` fills every parameter of a schema -- including the ones the reference
+initialises to zero (LoRA B, AdaLN modulation; lora.py:51, film.py:33-36), otherwise those
+paths would go untested (the reference's own tests randomise them for the same reason,
+tests/test_rollout.py:23-35).
+"""
+
+from __future__ import annotations
+
+import zlib
+from datetime import datetime
+from typing import Mapping, Sequence
+
+import numpy as np
+import torch
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def det_uniform(name: str, shape: Sequence[int], seed: int = 0) -> np.ndarray:
+    """float64 array of `shape`, i.i.d.-looking uniform on [-1, 1), a pure function of its args."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    with np.errstate(over="ignore"):
+        base = np.uint64(zlib.crc32(name.encode())) * np.uint64(0x100000001B3) + np.uint64(seed)
+        bits = _splitmix64(_splitmix64(np.full(1, base, dtype=np.uint64))[0]
+                           + np.arange(n, dtype=np.uint64))
+    u = (bits >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return (2.0 * u - 1.0).reshape(tuple(shape))
+
+
+def det_param(name: str, shape: Sequence[int], seed: int = 0) -> np.ndarray:
+    """A plausible parameter value for the schema entry `name`."""
+    u = det_uniform(name, shape, seed)
+    if len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        return u * np.sqrt(3.0 / fan_in)
+    if name.endswith(".weight"):  # 1-D weights are LayerNorm gains
+        return 1.0 + 0.1 * u
+    if name.endswith("surf_level_encoding"):
+        return 0.5 * u
+    return 0.1 * u  # biases
+
+
+def det_state_dict(specs, dtype=torch.float64, seed: int = 0) -> dict[str, torch.Tensor]:
+    """`specs`: iterable of objects with `.name` and `.shape` (aurora_amd ParamSpec) or pairs."""
+    out = {}
+    for s in specs:
+        name, shape = (s.name, s.shape) if hasattr(s, "name") else s
+        out[name] = torch.from_numpy(det_param(name, tuple(shape), seed)).to(dtype)
+    return out
+
+
+def det_inputs(surf_vars: Sequence[str], static_vars: Sequence[str], atmos_vars: Sequence[str],
+               B: int, T: int, H: int, W: int, levels: Sequence[float],
+               locations: Mapping[str, float], scales: Mapping[str, float], seed: int = 1,
+               positive: Sequence[str] = ()):
+    """Raw-unit inputs whose normalised values are det-uniform on [-1, 1) (|.| for `positive`).
+
+    Returns (surf, static, atmos, lat, lon, times) with fp64 tensors.
+    lat = linspace(90, -90, H), lon = linspace(0, 360, W + 1)[:-1] (README.md:87-97 recipe).
+    """
+    def lvl_key(lv):
+        v = round(float(lv), 3)
+        return (str(int(v)) if v % 1 == 0 else str(v)).replace(".", "_")
+
+    surf, static, atmos = {}, {}, {}
+    for v in surf_vars:
+        u = det_uniform(f"in.surf.{v}", (B, T, H, W), seed)
+        if v in positive:
+            u = np.abs(u)
+        surf[v] = torch.from_numpy(u * scales[v] + locations[v])
+    for v in static_vars:
+        u = det_uniform(f"in.static.{v}", (H, W), seed)
+        static[v] = torch.from_numpy(u * scales[v] + locations[v])
+    for v in atmos_vars:
+        u = det_uniform(f"in.atmos.{v}", (B, T, len(levels), H, W), seed)
+        if v in positive:
+            u = np.abs(u)
+        loc = np.array([locations[f"{v}_{lvl_key(lv)}"] for lv in levels])[:, None, None]
+        sc = np.array([scales[f"{v}_{lvl_key(lv)}"] for lv in levels])[:, None, None]
+        atmos[v] = torch.from_numpy(u * sc + loc)
+    lat = torch.linspace(90, -90, H, dtype=torch.float64)
+    lon = torch.linspace(0, 360, W + 1, dtype=torch.float64)[:-1]
+    times = tuple(datetime(2020, 6, 1 + b, 12, 0) for b in range(B))
+    return surf, static, atmos, lat, lon, times

@@ -1,0 +1,1 @@
+from torch.nn.init import trunc_normal_  # noqa: F401
