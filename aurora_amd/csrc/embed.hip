@@ -1,0 +1,308 @@
+// Encoder front end / decoder back end kernels (all HBM-bound, fp32 pixels on one side):
+//   * patchify            : Batch.normalise + pre-encoder transforms + unfold into the patch-embed
+//                           GEMM operand (LevelPatchEmbed's conv3d == GEMM over unfolded patches)
+//   * perceiver_attention : the tiny (3 x 13 / 13 x 3) per-column cross attentions
+//   * assemble_tokens     : surface/latent concat + position/scale/time embeddings
+//   * unpatchify          : head outputs -> (B, V, C, H, W) fields, clamp + Batch.unnormalise fused
+#include <math.h>
+
+#include "common.h"
+
+namespace aurora {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// patchify
+// ------------------------------------------------------------------------------------------------
+constexpr int MAX_VARS = 32;
+
+struct PatchVar {
+  const float* src; int64_t sb, st, sc, sh, sw;
+  const float* loc; const float* inv_scale;
+  int32_t transform; float tw0, tw1, tb;
+};
+struct PatchArgs {
+  PatchVar v[MAX_VARS];
+  void* out; int64_t Kpad; int k_offset; int K_total;
+  int n_vars, B, T, n_lvl, Hp, Wp, P;
+};
+
+__device__ __forceinline__ float patch_transform(float z, const PatchVar& d) {
+  if (d.transform == 1) return fmaxf(z, 0.f);
+  if (d.transform == 2) {
+    // reference aurora.py:733-742: Linear(2,1)([clamp(z,0,2.5), (log(max(z,eps)) - log eps) / -log eps])
+    z = fmaxf(z, 0.f);  // positive variables are clamped at 0 before the hook (aurora.py:301-317)
+    const float eps = 1e-4f, log_eps = -9.210340371976182f;  // log(1e-4)
+    const float f0 = fminf(z, 2.5f);
+    const float f1 = (logf(fmaxf(z, eps)) - log_eps) / (-log_eps);
+    return d.tw0 * f0 + d.tw1 * f1 + d.tb;
+  }
+  return z;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
+  // item = (row, q) with q = (v*T + t)*P + i fastest: neighbouring threads fill one output row.
+  const int L = p.Hp * p.Wp;
+  const int64_t rows = (int64_t)p.n_lvl * p.B * L;
+  const int q_per_row = p.n_vars * p.T * p.P;
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= rows * q_per_row) return;
+  const int64_t row = item / q_per_row;
+  const int q = (int)(item - row * q_per_row);
+  const int i = q % p.P;
+  const int vt = q / p.P;
+  const int t = vt % p.T, v = vt / p.T;
+  const int l = (int)(row % L);
+  const int64_t cb = row / L;  // rows are (level, batch, patch)
+  const int b = (int)(cb % p.B), c = (int)(cb / p.B);
+  const int hp = l / p.Wp, wp = l - hp * p.Wp;
+  const PatchVar& d = p.v[v];
+  const float loc = d.loc[c], inv = d.inv_scale[c];
+  const float* src = d.src + b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)(wp * p.P) * d.sw;
+  T* dst = reinterpret_cast<T*>(p.out) + row * p.Kpad + p.k_offset + (int64_t)vt * p.P * p.P + i * p.P;
+  for (int j = 0; j < p.P; ++j) {
+    const float z = (src[j * d.sw] - loc) * inv;
+    elem<T>::store(dst + j, patch_transform(z, d));
+  }
+  // zero the K padding of this row (done by the threads of the last variable's last piece)
+  if (q == q_per_row - 1 && p.k_offset + q_per_row * p.P == p.K_total) {
+    T* pad = reinterpret_cast<T*>(p.out) + row * p.Kpad;
+    for (int64_t k = p.K_total; k < p.Kpad; ++k) elem<T>::store(pad + k, 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// perceiver attention
+// ------------------------------------------------------------------------------------------------
+struct PercArgs {
+  const void* q; int64_t q_col_stride; const void* kv; void* out;
+  int B; int64_t cols_per_b, kv_bstride, kv_lstride; int Lq, Lk, heads;
+};
+
+template <typename T, int HDIM>
+__global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs p) {
+  const int inner = p.heads * HDIM;
+  const int64_t n_cols = (int64_t)p.B * p.cols_per_b;
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= n_cols * p.heads * p.Lq) return;
+  const int i = (int)(item % p.Lq);
+  const int h = (int)((item / p.Lq) % p.heads);
+  const int64_t col = item / ((int64_t)p.Lq * p.heads);
+  const int b = (int)(col / p.cols_per_b);
+  const int64_t l = col - (int64_t)b * p.cols_per_b;
+
+  const T* qp = reinterpret_cast<const T*>(p.q) + (col * p.q_col_stride + i) * inner + h * HDIM;
+  const float scale = rsqrtf((float)HDIM);
+  float qv[HDIM], o[HDIM];
+#pragma unroll
+  for (int d = 0; d < HDIM; d += 4) {
+    float t4[4];
+    load4(qp + d, t4);
+    qv[d] = t4[0] * scale; qv[d + 1] = t4[1] * scale; qv[d + 2] = t4[2] * scale; qv[d + 3] = t4[3] * scale;
+    o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
+  }
+  float mx = -INFINITY, sum = 0.f;
+  for (int j = 0; j < p.Lk; ++j) {
+    const T* kp = reinterpret_cast<const T*>(p.kv) + (b * p.kv_bstride + j * p.kv_lstride + l) * (2 * (int64_t)inner) + h * HDIM;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HDIM; d += 4) {
+      float t4[4];
+      load4(kp + d, t4);
+      s = fmaf(qv[d], t4[0], s); s = fmaf(qv[d + 1], t4[1], s);
+      s = fmaf(qv[d + 2], t4[2], s); s = fmaf(qv[d + 3], t4[3], s);
+    }
+    const float nm = fmaxf(mx, s);
+    const float corr = expf(mx - nm), e = expf(s - nm);
+    mx = nm;
+    sum = sum * corr + e;
+    const T* vp = kp + inner;
+#pragma unroll
+    for (int d = 0; d < HDIM; d += 4) {
+      float t4[4];
+      load4(vp + d, t4);
+      o[d] = fmaf(e, t4[0], o[d] * corr); o[d + 1] = fmaf(e, t4[1], o[d + 1] * corr);
+      o[d + 2] = fmaf(e, t4[2], o[d + 2] * corr); o[d + 3] = fmaf(e, t4[3], o[d + 3] * corr);
+    }
+  }
+  const float inv = 1.0f / sum;
+  T* op = reinterpret_cast<T*>(p.out) + (col * p.Lq + i) * inner + h * HDIM;
+#pragma unroll
+  for (int d = 0; d < HDIM; d += 4) {
+    const float t4[4] = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+    store4(op + d, t4);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// assemble tokens
+// ------------------------------------------------------------------------------------------------
+struct AsmArgs {
+  const float* surf; const float* agg; const float* pos_scale; const float* time_emb;
+  float* out_f32; void* out_t; int B, Cl; int64_t L; int D;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_kernel(const AsmArgs p) {
+  const int pieces = p.D >> 3;
+  const int64_t total = (int64_t)p.B * p.Cl * p.L * pieces;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += stride) {
+    const int e = (int)(it % pieces) * 8;
+    const int64_t tokn = it / pieces;        // (b, c, l)
+    const int64_t l = tokn % p.L;
+    const int c = (int)((tokn / p.L) % p.Cl);
+    const int b = (int)(tokn / (p.L * p.Cl));
+    float v[8], a[8];
+    if (c == 0) load8(p.surf + ((int64_t)b * p.L + l) * p.D + e, v);
+    else load8(p.agg + (((int64_t)b * p.L + l) * (p.Cl - 1) + (c - 1)) * p.D + e, v);
+    load8(p.pos_scale + l * p.D + e, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += a[j];
+    load8(p.time_emb + (int64_t)b * p.D + e, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += a[j];
+    store8(p.out_f32 + tokn * p.D + e, v);
+    if (p.out_t) store8(reinterpret_cast<T*>(p.out_t) + tokn * p.D + e, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// unpatchify
+// ------------------------------------------------------------------------------------------------
+struct UnpatchVar {
+  float* dst; const float* loc; const float* scale; int32_t clamp_min0, col0, lvl_stride, mod_col0;
+  const float* prev; int64_t prev_sb, prev_sc, prev_sh; const float* inv_scale; uint32_t clamp_max1_levels;
+};
+struct UnpatchArgs {
+  UnpatchVar v[MAX_VARS];
+  const float* y; int64_t ldy; int n_vars, B, n_lvl, Hp, Wp, P;
+};
+
+__global__ __launch_bounds__(256) void unpatchify_kernel(const UnpatchArgs p) {
+  // item = (v, b, c, hp, i, wp), wp fastest: neighbouring threads write one output row.
+  const int64_t per_var = (int64_t)p.B * p.n_lvl * p.Hp * p.P * p.Wp;
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= per_var * p.n_vars) return;
+  const int v = (int)(item / per_var);
+  int64_t r = item - (int64_t)v * per_var;
+  const int wp = (int)(r % p.Wp); r /= p.Wp;
+  const int i = (int)(r % p.P); r /= p.P;
+  const int hp = (int)(r % p.Hp); r /= p.Hp;
+  const int c = (int)(r % p.n_lvl);
+  const int b = (int)(r / p.n_lvl);
+  const UnpatchVar& d = p.v[v];
+  const int64_t L = (int64_t)p.Hp * p.Wp;
+  const float* row = p.y + (((int64_t)b * L + (int64_t)hp * p.Wp + wp) * p.n_lvl + c) * p.ldy + c * d.lvl_stride + i * p.P;
+  const float* src = row + d.col0;
+  const int64_t W = (int64_t)p.Wp * p.P, H = (int64_t)p.Hp * p.P;
+  const int64_t hh = (int64_t)hp * p.P + i, ww = (int64_t)wp * p.P;
+  float* dst = d.dst + (((int64_t)b * p.n_lvl + c) * H + hh) * W + ww;
+  const float loc = d.loc[c], sc = d.scale[c];
+  const bool has_mod = d.mod_col0 >= 0;
+  const float* mod = row + (has_mod ? d.mod_col0 : 0);
+  const float* prev = has_mod ? d.prev + b * d.prev_sb + c * d.prev_sc + hh * d.prev_sh + ww : nullptr;
+  const float inv = has_mod ? d.inv_scale[c] : 0.f;
+  const bool cap1 = (d.clamp_max1_levels >> c) & 1u;
+  for (int j = 0; j < p.P; ++j) {
+    float z = src[j];
+    if (has_mod) z = z + (1.0f + mod[j]) * ((prev[j] - loc) * inv);
+    if (cap1) z = fminf(z, 1.0f);
+    if (d.clamp_min0) z = fmaxf(z, 0.f);
+    dst[j] = z * sc + loc;
+  }
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+}  // namespace aurora
+
+using namespace aurora;
+
+extern "C" int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, void* out, int64_t Kpad,
+                                   int k_offset, int K_total, int B, int T, int n_lvl, int Hp, int Wp, int P,
+                                   int dtype, void* stream) {
+  AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "patchify: bad dtype");
+  AURORA_CHECK_ARG(n_vars > 0 && n_vars <= MAX_VARS, "patchify: %d variables per call (max %d)", n_vars, MAX_VARS);
+  AURORA_CHECK_ARG(k_offset >= 0 && k_offset + n_vars * T * P * P <= K_total && K_total <= Kpad,
+                   "patchify: column range does not fit (k_offset=%d K_total=%d Kpad=%lld)", k_offset, K_total,
+                   (long long)Kpad);
+  PatchArgs p;
+  for (int v = 0; v < n_vars; ++v) {
+    const aurora_patch_var& s = desc[v];
+    p.v[v] = PatchVar{s.src, s.stride_b, s.stride_t, s.stride_c, s.stride_h, s.stride_w,
+                      s.loc, s.inv_scale, s.transform, s.tw0, s.tw1, s.tb};
+  }
+  p.out = out; p.Kpad = Kpad; p.k_offset = k_offset; p.K_total = K_total;
+  p.n_vars = n_vars; p.B = B; p.T = T; p.n_lvl = n_lvl; p.Hp = Hp; p.Wp = Wp; p.P = P;
+  const int64_t items = (int64_t)n_lvl * B * Hp * Wp * n_vars * T * P;
+  AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "patchify: bad problem size");
+  if (dtype == AURORA_F32)
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+  else
+    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+  return check_launch("patchify");
+}
+
+extern "C" int aurora_hip_perceiver_attention(const void* q, int64_t q_col_stride, const void* kv, void* out,
+                                              int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
+                                              int Lq, int Lk, int heads, int head_dim, int dtype, void* stream) {
+  AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "perceiver_attention: bad dtype");
+  AURORA_CHECK_ARG(Lq > 0 && Lk > 0 && heads > 0 && B > 0 && cols_per_b > 0, "perceiver_attention: empty problem");
+  PercArgs p{q, q_col_stride, kv, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads};
+  const int64_t items = (int64_t)B * cols_per_b * heads * Lq;
+  const dim3 grid(blocks_for(items, 256)), block(256);
+#define AURORA_PERC(TT, HDIM) hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM>), grid, block, 0, as_stream(stream), p)
+  if (dtype == AURORA_F32) {
+    switch (head_dim) {
+      case 16: AURORA_PERC(float, 16); break;
+      case 32: AURORA_PERC(float, 32); break;
+      case 64: AURORA_PERC(float, 64); break;
+      case 128: AURORA_PERC(float, 128); break;
+      default: AURORA_CHECK_ARG(false, "perceiver_attention: head_dim %d not in {16,32,64,128}", head_dim);
+    }
+  } else {
+    switch (head_dim) {
+      case 16: AURORA_PERC(bf16_t, 16); break;
+      case 32: AURORA_PERC(bf16_t, 32); break;
+      case 64: AURORA_PERC(bf16_t, 64); break;
+      case 128: AURORA_PERC(bf16_t, 128); break;
+      default: AURORA_CHECK_ARG(false, "perceiver_attention: head_dim %d not in {16,32,64,128}", head_dim);
+    }
+  }
+#undef AURORA_PERC
+  return check_launch("perceiver_attention");
+}
+
+extern "C" int aurora_hip_assemble_tokens(const float* surf, const float* agg, const float* pos_scale,
+                                          const float* time_emb, float* out_f32, void* out_t, int B, int Cl,
+                                          int64_t L, int D, int dtype, void* stream) {
+  AURORA_CHECK_ARG(D % 8 == 0 && Cl >= 2, "assemble_tokens: D=%d must be a multiple of 8, Cl=%d >= 2", D, Cl);
+  AsmArgs p{surf, agg, pos_scale, time_emb, out_f32, out_t, B, Cl, L, D};
+  const int64_t total = (int64_t)B * Cl * L * (D / 8);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (dtype == AURORA_F32) {
+    p.out_t = nullptr;  // the fp32 stream is its own GEMM operand
+    hipLaunchKernelGGL(assemble_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), p);
+  } else {
+    hipLaunchKernelGGL(assemble_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), p);
+  }
+  return check_launch("assemble_tokens");
+}
+
+extern "C" int aurora_hip_unpatchify(const float* y, int64_t ldy, const aurora_unpatch_var* desc, int n_vars,
+                                     int B, int n_lvl, int Hp, int Wp, int P, void* stream) {
+  AURORA_CHECK_ARG(n_vars > 0 && n_vars <= MAX_VARS, "unpatchify: %d variables per call (max %d)", n_vars, MAX_VARS);
+  UnpatchArgs p;
+  for (int v = 0; v < n_vars; ++v)
+    p.v[v] = UnpatchVar{desc[v].dst, desc[v].loc, desc[v].scale, desc[v].clamp_min0, desc[v].col0,
+                        desc[v].lvl_stride, desc[v].mod_col0, desc[v].prev, desc[v].prev_sb, desc[v].prev_sc,
+                        desc[v].prev_sh, desc[v].inv_scale, desc[v].clamp_max1_levels};
+  p.y = y; p.ldy = ldy; p.n_vars = n_vars; p.B = B; p.n_lvl = n_lvl; p.Hp = Hp; p.Wp = Wp; p.P = P;
+  const int64_t items = (int64_t)n_vars * B * n_lvl * Hp * P * Wp;
+  AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "unpatchify: bad problem size");
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+  return check_launch("unpatchify");
+}

@@ -1,0 +1,313 @@
+// Dense linear layers on the gfx950 matrix cores:  C = act(A . W^T + bias) (+ residual).
+//
+// One kernel template serves bf16 (v_mfma_f32_16x16x32_bf16) and fp32
+// (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains) because both are tiled in BYTES: a K-tile
+// is 128 bytes of every operand row (64 bf16 / 32 fp32), staged by 16-byte LDS-DMA pieces
+// (global_load_lds_dwordx4, no VGPR round trip) into two LDS buffers per operand.
+//
+// Block tile 128 (m) x 128 (n), 256 threads = 4 waves as 2 (m) x 2 (n), wave tile 64 x 64 =
+// 4 x 4 MFMA fragments of 16 x 16.  The MFMA "A" operand is the WEIGHT tile and the "B"
+// operand the activation tile, i.e. every fragment holds C^T: lane (j = lane & 15, g = lane >> 4)
+// owns activation row m = 16*fm + j and 4 consecutive output features per fragment.  Weight rows
+// are interleaved over the 4 n-fragments (row = 16*(i>>2) + 4*fn + (i&3) for operand row i), so
+// that the lane ends up with 16 CONSECUTIVE output features n = 16*g + 0..15 of one row: the
+// epilogue (bias, exact GELU, residual, dual-dtype store) then works on whole 32/64-byte row
+// pieces with 16-byte stores.
+//
+// LDS image of a tile: [128 rows][8 chunks of 16 B], chunk c of row r stored at position
+// c ^ f(r).  LDS-DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE
+// address and again on the fragment read (both sides or neither).  f is chosen per operand so
+// that the 16 rows touched by one ds_read_b128 lane group fall on 16 distinct 16-byte bank slots:
+//   activations: rows i, i+1, ...          f(r) = r & 7
+//   weights    : rows 16a + 4fn + b        f(r) = ((r >> 4) & 3) << 1 | ((r >> 1) & 1)
+//
+// Workgroup ids are remapped so that each XCD (8 of them, private L2s, block b runs on XCD b % 8)
+// owns a contiguous range of tiles with the n-tiles of one m-tile adjacent: the activation tile
+// is then fetched from HBM once per XCD and re-used out of that XCD's L2.
+#include "common.h"
+
+namespace aurora {
+
+namespace {
+
+constexpr int BM = 128;       // activation rows per block
+constexpr int BN = 128;       // output features per block
+constexpr int ROW_BYTES = 128;  // bytes of K per tile row
+constexpr int TILE_BYTES = 128 * ROW_BYTES;  // 16 KiB per operand per buffer
+constexpr int THREADS = 256;
+
+struct LinearArgs {
+  const char* A; int64_t lda_b;   // byte strides
+  const char* W; int64_t ldw_b;
+  const float* bias;
+  char* C; int64_t ldc;           // element strides from here on
+  char* C2; int64_t ldc2;
+  const float* res; int64_t ldr;
+  int64_t M; int N; int k_tiles; int act;
+  int tiles_n; int64_t n_blocks;
+  int vec_store;                  // 1: every C/C2/res row piece is 16-byte aligned
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ int swz_x(int row) { return row & 7; }
+__device__ __forceinline__ int swz_w(int row) { return (((row >> 4) & 3) << 1) | ((row >> 1) & 1); }
+
+// One 16 x 16 x (128 bytes of K / 2) MFMA step on 16-byte operand pieces.
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  __device__ static __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // The K order inside a tile is free as long as both operands agree: lane group g supplies
+  // k = 16*chunk + 4*g + s to the s-th of four 16x16x4 steps.
+  __device__ static __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void store16(T* dst, const float (&v)[16], bool vec, int n_left);
+
+template <>
+__device__ __forceinline__ void store16<float>(float* dst, const float (&v)[16], bool vec, int n_left) {
+  if (vec && n_left >= 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      reinterpret_cast<f32x4*>(dst)[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  } else {
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (t < n_left) dst[t] = v[t];
+  }
+}
+template <>
+__device__ __forceinline__ void store16<bf16_t>(bf16_t* dst, const float (&v)[16], bool vec, int n_left) {
+  if (vec && n_left >= 16) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      reinterpret_cast<u32x4*>(dst)[q] =
+          u32x4{pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
+                pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7])};
+  } else {
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (t < n_left) dst[t] = f32_to_bf16(v[t]);
+  }
+}
+
+template <typename T> struct Other;
+template <> struct Other<float> { typedef bf16_t type; };
+template <> struct Other<bf16_t> { typedef float type; };
+
+template <typename T>
+__global__ __launch_bounds__(THREADS, 2) void linear_kernel(const LinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Per buffer: X tile then W tile; 2 buffers.
+  auto lds_x = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
+  auto lds_w = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware tile assignment (bijective for any block count) ----
+  const uint32_t bid = blockIdx.x, nb = (uint32_t)p.n_blocks;
+  const uint32_t q8 = nb >> 3, r8 = nb & 7;
+  const uint32_t xcd = bid & 7, idx = bid >> 3;
+  const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const uint32_t tile_m = logical / (uint32_t)p.tiles_n;
+  const int tile_n = (int)(logical - tile_m * (uint32_t)p.tiles_n);
+  const int64_t m0 = (int64_t)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- per-thread staging addresses: 4 pieces of X and 4 of W per K-tile ----
+  const char* src_x[4];
+  const char* src_w[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r * 32 + (tid >> 3);
+    const int c = tid & 7;
+    int64_t gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + row;
+    gn = gn < p.N ? gn : p.N - 1;
+    src_x[r] = p.A + gm * p.lda_b + ((c ^ swz_x(row)) << 4);
+    src_w[r] = p.W + (int64_t)gn * p.ldw_b + ((c ^ swz_w(row)) << 4);
+  }
+
+  auto stage = [&](int kt, int buf) {
+    const int64_t koff = (int64_t)kt * ROW_BYTES;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // wave-uniform LDS base; the hardware adds lane * 16.
+      const int base = (r * 256 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src_x[r] + koff),
+          (lds_ptr_t)(lds_x(buf) + base), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src_w[r] + koff),
+          (lds_ptr_t)(lds_w(buf) + base), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside a tile), one per (fragment, k-half) ----
+  const int i16 = lane & 15, g = lane >> 4;
+  int off_w[4][2], off_x[4][2];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int row_w = wn * 64 + 16 * (i16 >> 2) + 4 * f + (i16 & 3);
+    const int row_x = wm * 64 + 16 * f + i16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = g + 4 * ks;
+      off_w[f][ks] = row_w * ROW_BYTES + ((c ^ swz_w(row_w)) << 4);
+      off_x[f][ks] = row_x * ROW_BYTES + ((c ^ swz_x(row_x)) << 4);
+    }
+  }
+
+  f32x4 acc[4][4];  // [fn][fm]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < p.k_tiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < p.k_tiles) stage(kt + 1, buf ^ 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fw[4], fx[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        fw[f] = *reinterpret_cast<const u32x4*>(lds_w(buf) + off_w[f][ks]);
+        fx[f] = *reinterpret_cast<const u32x4*>(lds_x(buf) + off_x[f][ks]);
+      }
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) acc[fn][fm] = Mma<T>::run(fw[fn], fx[fm], acc[fn][fm]);
+    }
+    // The LDS-DMA of tile kt+1 must have landed, and every wave must be done reading tile kt,
+    // before the next iteration reads one buffer and overwrites the other.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns row m (per fm) x 16 consecutive features ----
+  const int nbase = n0 + wn * 64 + 16 * g;
+  const int n_left = p.N - nbase;
+  if (n_left <= 0) return;
+  float bias_v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) bias_v[t] = (p.bias && t < n_left) ? p.bias[nbase + t] : 0.f;
+  const bool vec = p.vec_store != 0;
+  typedef typename Other<T>::type T2;
+
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int64_t m = m0 + wm * 64 + 16 * fm + i16;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
+      v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
+      v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
+      v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
+    }
+    if (p.act == AURORA_ACT_GELU) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = gelu_erf(v[t]);
+    } else if (p.act == AURORA_ACT_SILU) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
+    }
+    if (p.res) {
+      const float* rp = p.res + m * p.ldr + nbase;
+      if (vec && n_left >= 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 rv = reinterpret_cast<const f32x4*>(rp)[q];
+          v[4 * q] += rv.x; v[4 * q + 1] += rv.y; v[4 * q + 2] += rv.z; v[4 * q + 3] += rv.w;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (t < n_left) v[t] += rp[t];
+      }
+    }
+    store16<T>(reinterpret_cast<T*>(p.C) + m * p.ldc + nbase, v, vec, n_left);
+    if (p.C2) store16<T2>(reinterpret_cast<T2*>(p.C2) + m * p.ldc2 + nbase, v, vec, n_left);
+  }
+}
+
+}  // namespace
+
+}  // namespace aurora
+
+using namespace aurora;
+
+extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int64_t ldw,
+                                 const float* bias, void* C, int64_t ldc, void* C2, int64_t ldc2,
+                                 const float* residual, int64_t ldr, int64_t M, int N, int K,
+                                 int dtype, int act, void* stream) {
+  AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "linear: bad dtype %d", dtype);
+  AURORA_CHECK_ARG(M > 0 && N > 0 && K > 0, "linear: empty problem M=%lld N=%d K=%d", (long long)M, N, K);
+  const int es = dtype == AURORA_F32 ? 4 : 2, es2 = dtype == AURORA_F32 ? 2 : 4;
+  AURORA_CHECK_ARG(((int64_t)K * es) % ROW_BYTES == 0,
+                   "linear: K=%d must be a multiple of %d elements", K, ROW_BYTES / es);
+  AURORA_CHECK_ARG((lda * es) % 16 == 0 && (ldw * es) % 16 == 0 && lda >= K && ldw >= K,
+                   "linear: operand strides must be 16-byte multiples >= K");
+  AURORA_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0, "linear: unaligned operand");
+  AURORA_CHECK_ARG(act >= AURORA_ACT_NONE && act <= AURORA_ACT_SILU, "linear: bad activation %d", act);
+  AURORA_CHECK_ARG(C != nullptr && ldc >= N && (!C2 || ldc2 >= N) && (!residual || ldr >= N || ldr == 0),
+                   "linear: bad output strides");
+
+  LinearArgs p;
+  p.A = (const char*)A; p.lda_b = lda * es;
+  p.W = (const char*)W; p.ldw_b = ldw * es;
+  p.bias = bias;
+  p.C = (char*)C; p.ldc = ldc; p.C2 = (char*)C2; p.ldc2 = ldc2;
+  p.res = residual; p.ldr = ldr;
+  p.M = M; p.N = N; p.k_tiles = (int)(((int64_t)K * es) / ROW_BYTES); p.act = act;
+  p.tiles_n = (N + BN - 1) / BN;
+  p.n_blocks = ((M + BM - 1) / BM) * p.tiles_n;
+  bool vec = ((uintptr_t)C % 16) == 0 && (ldc * es) % 16 == 0;
+  if (C2) vec = vec && ((uintptr_t)C2 % 16) == 0 && (ldc2 * es2) % 16 == 0;
+  if (residual) vec = vec && ((uintptr_t)residual % 16) == 0 && (ldr * 4) % 16 == 0;
+  p.vec_store = vec ? 1 : 0;
+  AURORA_CHECK_ARG(p.n_blocks < (int64_t)1 << 31, "linear: too many tiles");
+
+  const size_t lds = 4 * TILE_BYTES;
+  dim3 grid((unsigned)p.n_blocks), block(THREADS);
+  if (dtype == AURORA_F32) {
+    static bool attr_f = false;
+    if (!attr_f) {
+      (void)hipFuncSetAttribute((const void*)linear_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_f = true;
+    }
+    hipLaunchKernelGGL(linear_kernel<float>, grid, block, lds, as_stream(stream), p);
+  } else {
+    static bool attr_b = false;
+    if (!attr_b) {
+      (void)hipFuncSetAttribute((const void*)linear_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_b = true;
+    }
+    hipLaunchKernelGGL(linear_kernel<bf16_t>, grid, block, lds, as_stream(stream), p);
+  }
+  return check_launch("linear");
+}

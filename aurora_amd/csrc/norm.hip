@@ -1,0 +1,240 @@
+// Row-wise layer normalisations of the backbone, all HBM-bound streaming kernels:
+//   * layernorm      : out = res + LN(y) * gain + shift        (AdaLN / affine LN + residual)
+//   * merge_ln       : 2x2 spatial gather -> LN(4D)            (front half of PatchMerging3D)
+//   * split_ln       : pixel shuffle + crop -> LN(D/2)          (middle of PatchSplitting3D)
+// One wavefront owns one row: the row lives in registers (8-element / 16- or 32-byte pieces per
+// lane, lane-interleaved so every load instruction covers a contiguous 1-2 KiB), statistics are
+// two-pass fp32 (mean, then centred second moment) reduced with xor-shuffles.  4 rows per block.
+#include "common.h"
+
+namespace aurora {
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;
+
+// Normalise a row held as v[c][0..7] for pieces c = lane + 64*i, i < MAXC.
+template <int MAXC>
+__device__ __forceinline__ void row_stats(const float (&v)[MAXC][8], int lane, int n_pieces, float inv_d, float eps,
+                                          float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < n_pieces) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  mean = wave_sum(s) * inv_d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < n_pieces) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[i][j] - mean;
+        q = fmaf(d, d, q);
+      }
+    }
+  rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+}
+
+struct LnArgs {
+  const void* y; int64_t ldy; const float* gain; const float* shift;
+  const float* res; int64_t ldr; int64_t res_mod;
+  float* out_f32; int64_t ldo; void* out_t; int64_t ldt;
+  int64_t M; int D; float eps;
+};
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int n_pieces = p.D >> 3;
+  const T* yr = reinterpret_cast<const T*>(p.y) + row * p.ldy;
+  float v[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < n_pieces) load8(yr + (lane + 64 * i) * 8, v[i]);
+  float mean, rstd;
+  row_stats<MAXC>(v, lane, n_pieces, 1.0f / p.D, p.eps, mean, rstd);
+
+  const float* rr = nullptr;
+  if (p.res) rr = p.res + (p.res_mod > 0 ? row % p.res_mod : row) * p.ldr;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int e = (lane + 64 * i) * 8;
+    if (lane + 64 * i < n_pieces) {
+      float gn[8], sh[8], o[8];
+      if (p.gain) load8(p.gain + e, gn);
+      if (p.shift) load8(p.shift + e, sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = (v[i][j] - mean) * rstd;
+        if (p.gain) t *= gn[j];
+        if (p.shift) t += sh[j];
+        o[j] = t;
+      }
+      if (rr) {
+        float r8[8];
+        load8(rr + e, r8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += r8[j];
+      }
+      if (p.out_f32) store8(p.out_f32 + row * p.ldo + e, o);
+      if (p.out_t) store8(reinterpret_cast<T*>(p.out_t) + row * p.ldt + e, o);
+    }
+  }
+}
+
+struct MergeArgs {
+  const float* x; const float* w; const float* b; void* out;
+  int B, C, H, W, D, H2, W2; float eps;
+};
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void merge_ln_kernel(const MergeArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int64_t rows = (int64_t)p.B * p.C * p.H2 * p.W2;
+  if (row >= rows) return;
+  const int w2 = (int)(row % p.W2);
+  const int h2 = (int)((row / p.W2) % p.H2);
+  const int64_t bc = row / ((int64_t)p.W2 * p.H2);
+  const int D4 = 4 * p.D, n_pieces = D4 >> 3;
+  float v[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int e = (lane + 64 * i) * 8;
+    if (lane + 64 * i < n_pieces) {
+      const int seg = e / p.D, d = e - seg * p.D;  // seg = dh*2 + dw
+      const int hh = 2 * h2 + (seg >> 1), ww = 2 * w2 + (seg & 1);
+      if (hh < p.H && ww < p.W) {
+        load8(p.x + ((bc * p.H + hh) * p.W + ww) * p.D + d, v[i]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = 0.f;  // bottom/right zero padding of odd grids
+      }
+    }
+  }
+  float mean, rstd;
+  row_stats<MAXC>(v, lane, n_pieces, 1.0f / D4, p.eps, mean, rstd);
+  T* orow = reinterpret_cast<T*>(p.out) + row * D4;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int e = (lane + 64 * i) * 8;
+    if (lane + 64 * i < n_pieces) {
+      float gn[8], sh[8], o[8];
+      load8(p.w + e, gn);
+      load8(p.b + e, sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gn[j] + sh[j];
+      store8(orow + e, o);
+    }
+  }
+}
+
+struct SplitArgs {
+  const void* y; const float* w; const float* b; void* out;
+  int B, C, H, W, Dq, Ho, Wo; float eps;
+};
+
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void split_ln_kernel(const SplitArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  const int64_t rows = (int64_t)p.B * p.C * p.Ho * p.Wo;
+  if (row >= rows) return;
+  const int wo = (int)(row % p.Wo);
+  const int ho = (int)((row / p.Wo) % p.Ho);
+  const int64_t bc = row / ((int64_t)p.Wo * p.Ho);
+  const int n_pieces = p.Dq >> 3;
+  const int seg = (ho & 1) * 2 + (wo & 1);
+  const T* src = reinterpret_cast<const T*>(p.y) + ((bc * p.H + (ho >> 1)) * p.W + (wo >> 1)) * (4 * (int64_t)p.Dq) +
+                 (int64_t)seg * p.Dq;
+  float v[MAXC][8];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < n_pieces) load8(src + (lane + 64 * i) * 8, v[i]);
+  float mean, rstd;
+  row_stats<MAXC>(v, lane, n_pieces, 1.0f / p.Dq, p.eps, mean, rstd);
+  T* orow = reinterpret_cast<T*>(p.out) + row * p.Dq;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int e = (lane + 64 * i) * 8;
+    if (lane + 64 * i < n_pieces) {
+      float gn[8], sh[8], o[8];
+      load8(p.w + e, gn);
+      load8(p.b + e, sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gn[j] + sh[j];
+      store8(orow + e, o);
+    }
+  }
+}
+
+inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+
+}  // namespace
+}  // namespace aurora
+
+using namespace aurora;
+
+// Pick the register-tile instantiation for a row of D elements: MAXC pieces of 8 per lane.
+#define AURORA_DISPATCH_ROW(KERNEL, T, D, ...)                                                        \
+  do {                                                                                                \
+    if ((D) <= 512) hipLaunchKernelGGL((KERNEL<T, 1>), __VA_ARGS__);                                  \
+    else if ((D) <= 1024) hipLaunchKernelGGL((KERNEL<T, 2>), __VA_ARGS__);                            \
+    else if ((D) <= 2048) hipLaunchKernelGGL((KERNEL<T, 4>), __VA_ARGS__);                            \
+    else hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__);                                             \
+  } while (0)
+
+extern "C" int aurora_hip_layernorm(const void* y, int64_t ldy, const float* gain, const float* shift,
+                                    const float* res, int64_t ldr, int64_t res_mod, float* out_f32,
+                                    int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D, float eps,
+                                    int dtype, void* stream) {
+  AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "layernorm: bad dtype");
+  AURORA_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 4096, "layernorm: D=%d must be a multiple of 8, <= 4096", D);
+  const int es = dtype == AURORA_F32 ? 4 : 2;
+  AURORA_CHECK_ARG((ldy * es) % 16 == 0 && (uintptr_t)y % 16 == 0, "layernorm: unaligned input rows");
+  AURORA_CHECK_ARG((!res || ((ldr * 4) % 16 == 0 && (uintptr_t)res % 16 == 0)) &&
+                       (!out_f32 || ((ldo * 4) % 16 == 0 && (uintptr_t)out_f32 % 16 == 0)) &&
+                       (!out_t || ((ldt * es) % 16 == 0 && (uintptr_t)out_t % 16 == 0)),
+                   "layernorm: unaligned residual/output rows");
+  AURORA_CHECK_ARG(out_f32 || out_t, "layernorm: no output");
+  if (M <= 0) return AURORA_OK;
+  LnArgs p{y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps};
+  if (dtype == AURORA_F32)
+    AURORA_DISPATCH_ROW(layernorm_kernel, float, D, dim3(row_blocks(M)), dim3(256), 0, as_stream(stream), p);
+  else
+    AURORA_DISPATCH_ROW(layernorm_kernel, bf16_t, D, dim3(row_blocks(M)), dim3(256), 0, as_stream(stream), p);
+  return check_launch("layernorm");
+}
+
+extern "C" int aurora_hip_merge_ln(const float* x, const float* ln_w, const float* ln_b, void* out, int B, int C,
+                                   int H, int W, int D, float eps, int dtype, void* stream) {
+  AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "merge_ln: bad dtype");
+  AURORA_CHECK_ARG(D % 8 == 0 && 4 * D <= 4096, "merge_ln: D=%d must be a multiple of 8 with 4D <= 4096", D);
+  AURORA_CHECK_ARG(H > 1 && W > 1, "merge_ln: grid %dx%d too small", H, W);
+  MergeArgs p{x, ln_w, ln_b, out, B, C, H, W, D, (H + 1) / 2, (W + 1) / 2, eps};
+  const int64_t rows = (int64_t)B * C * p.H2 * p.W2;
+  if (dtype == AURORA_F32)
+    AURORA_DISPATCH_ROW(merge_ln_kernel, float, 4 * D, dim3(row_blocks(rows)), dim3(256), 0, as_stream(stream), p);
+  else
+    AURORA_DISPATCH_ROW(merge_ln_kernel, bf16_t, 4 * D, dim3(row_blocks(rows)), dim3(256), 0, as_stream(stream), p);
+  return check_launch("merge_ln");
+}
+
+extern "C" int aurora_hip_split_ln(const void* y, const float* ln_w, const float* ln_b, void* out, int B, int C,
+                                   int H, int W, int Dq, int crop_h, int crop_w, float eps, int dtype,
+                                   void* stream) {
+  AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "split_ln: bad dtype");
+  AURORA_CHECK_ARG(Dq % 8 == 0 && Dq <= 4096, "split_ln: Dq=%d must be a multiple of 8, <= 4096", Dq);
+  AURORA_CHECK_ARG(crop_h >= 0 && crop_h <= 1 && crop_w >= 0 && crop_w <= 1, "split_ln: crop must be 0 or 1");
+  SplitArgs p{y, ln_w, ln_b, out, B, C, H, W, Dq, 2 * H - crop_h, 2 * W - crop_w, eps};
+  const int64_t rows = (int64_t)B * C * p.Ho * p.Wo;
+  if (dtype == AURORA_F32)
+    AURORA_DISPATCH_ROW(split_ln_kernel, float, Dq, dim3(row_blocks(rows)), dim3(256), 0, as_stream(stream), p);
+  else
+    AURORA_DISPATCH_ROW(split_ln_kernel, bf16_t, Dq, dim3(row_blocks(rows)), dim3(256), 0, as_stream(stream), p);
+  return check_launch("split_ln");
+}

@@ -1,0 +1,102 @@
+// Error plumbing and small utility entry points of libaurora_hip.so.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace aurora {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return AURORA_E_LAUNCH;
+  }
+  return AURORA_OK;
+}
+
+namespace {
+
+template <typename S, typename D>
+__global__ void convert_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n8) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    float v[8];
+    load8(src + i * 8, v);
+    store8(dst + i * 8, v);
+  }
+}
+template <typename S, typename D>
+__global__ void convert_tail_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t from, int64_t n) {
+  const int64_t i = from + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) elem<D>::store(dst + i, elem<S>::load(src + i));
+}
+
+template <typename T>
+__global__ void copy2d_kernel(const T* __restrict__ src, int64_t lds_, T* __restrict__ dst, int64_t ldd,
+                              int64_t rows, int64_t cols16) {
+  // one 16-byte piece per thread, grid-stride over rows * cols16 pieces
+  const int64_t total = rows * cols16, stride = (int64_t)gridDim.x * blockDim.x;
+  constexpr int E = 16 / sizeof(T);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / cols16, c = i - r * cols16;
+    *reinterpret_cast<u32x4*>(dst + r * ldd + c * E) = *reinterpret_cast<const u32x4*>(src + r * lds_ + c * E);
+  }
+}
+
+}  // namespace
+}  // namespace aurora
+
+using namespace aurora;
+
+extern "C" const char* aurora_hip_last_error(void) { return g_err; }
+extern "C" int aurora_hip_version(void) { return 1; }
+
+extern "C" int aurora_hip_convert(const void* src, void* dst, int64_t n, int src_dtype, void* stream) {
+  AURORA_CHECK_ARG(src_dtype == AURORA_F32 || src_dtype == AURORA_BF16, "convert: bad dtype");
+  if (n <= 0) return AURORA_OK;
+  const bool al = ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+  const int64_t n8 = al ? n / 8 : 0;
+  const int64_t tail = n - n8 * 8;
+  const int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+  if (src_dtype == AURORA_F32) {
+    if (n8) hipLaunchKernelGGL((convert_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream),
+                               (const float*)src, (bf16_t*)dst, n8);
+    if (tail) hipLaunchKernelGGL((convert_tail_kernel<float, bf16_t>), dim3((unsigned)((tail + 255) / 256)), dim3(256), 0,
+                                 as_stream(stream), (const float*)src, (bf16_t*)dst, n8 * 8, n);
+  } else {
+    if (n8) hipLaunchKernelGGL((convert_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, as_stream(stream),
+                               (const bf16_t*)src, (float*)dst, n8);
+    if (tail) hipLaunchKernelGGL((convert_tail_kernel<bf16_t, float>), dim3((unsigned)((tail + 255) / 256)), dim3(256), 0,
+                                 as_stream(stream), (const bf16_t*)src, (float*)dst, n8 * 8, n);
+  }
+  return check_launch("convert");
+}
+
+extern "C" int aurora_hip_copy2d(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows,
+                                 int64_t cols, int dtype, void* stream) {
+  AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "copy2d: bad dtype");
+  const int es = dtype == AURORA_F32 ? 4 : 2;
+  AURORA_CHECK_ARG((cols * es) % 16 == 0 && (lds_ * es) % 16 == 0 && (ldd * es) % 16 == 0 &&
+                       (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0,
+                   "copy2d: rows must be 16-byte multiples and aligned");
+  if (rows <= 0 || cols <= 0) return AURORA_OK;
+  const int64_t cols16 = cols * es / 16, total = rows * cols16;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (dtype == AURORA_F32)
+    hipLaunchKernelGGL(copy2d_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)src, lds_,
+                       (float*)dst, ldd, rows, cols16);
+  else
+    hipLaunchKernelGGL(copy2d_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)src, lds_,
+                       (bf16_t*)dst, ldd, rows, cols16);
+  return check_launch("copy2d");
+}

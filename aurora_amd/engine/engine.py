@@ -1,0 +1,776 @@
+"""The MI355X engine: packs an `Aurora` model's weights for the HIP library and runs the step.
+
+`Engine.step(batch)` is what `Aurora.forward` executes.  It reproduces the data flow of the
+reference's forward (aurora/model/aurora.py:265-392; encoder.py:198-366; swin3d.py:884-936,
+440-509; decoder.py:168-276) as a sequence of libaurora_hip calls on the current HIP stream:
+
+  encoder   patchify(+normalise) -> GEMM -> surface MLP/LN, per-level GEMMs -> Perceiver level
+            aggregation (GEMM, small cross attention, GEMM, LN, MLP, LN) -> token assembly with
+            the cached position / scale / time embeddings
+  backbone  per Swin block: qkv GEMM -> window attention (gather/scatter through the host
+            geometry tables) -> proj GEMM -> AdaLN + residual -> fc1 GEMM (GELU) -> fc2 GEMM ->
+            AdaLN + residual; merge / split around the U-net stages
+  decoder   head GEMM + unpatchify (surface), Perceiver level de-aggregation, head GEMM +
+            unpatchify with clamp / un-normalise fused
+
+Everything that does not depend on the input fields is computed once and cached on the device:
+AdaLN modulation vectors (lead time is a model constant), Fourier position / scale tables per
+grid, pressure-level embeddings per level set, LoRA-merged weight sets per roll-out phase.
+
+Precision: parameters must be fp32.  With `autocast=False` everything runs in fp32 (fp32-input
+MFMA, exact fp32 FMA chains).  With `autocast=True` the backbone GEMMs and attention take bf16
+operands with fp32 accumulation while LayerNorm statistics, softmax and the residual stream stay
+fp32 -- the semantics of the reference's `torch.autocast` region (aurora.py:327-343); encoder and
+decoder stay fp32 like upstream.
+
+torch is used here for device memory (torch.empty / views), layout plumbing at pack time
+(cat / pad / transpose of weights) and streams -- no torch arithmetic on the per-step path.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+from collections import OrderedDict
+from datetime import timedelta
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from aurora_amd import normalisation
+from aurora_amd.batch import Batch, Metadata
+from aurora_amd.engine import encodings, geometry, lib
+from aurora_amd.model.schema import DYNAMIC_VARS, LORA_ALPHA, LORA_RANK
+from aurora_amd.normalisation import level_to_str
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Engine:
+    def __init__(self, model) -> None:
+        lib.load()  # fail loudly if libaurora_hip.so is missing
+        self.model = model
+        self.cfg = model.config
+        p = next(model.parameters())
+        if p.dtype != F32:
+            raise NotImplementedError(
+                f"aurora_amd computes in fp32 (or bf16 backbone with autocast=True); parameters "
+                f"are {p.dtype}. Keep the model in float32."
+            )
+        if model.variant == "wave":
+            raise NotImplementedError("AuroraWave hooks are not implemented in the HIP engine yet.")
+        self.device = p.device
+        self.bb_dtype = BF16 if model.autocast else F32
+        cfg = self.cfg
+        for heads, dim in zip(cfg.encoder_num_heads + cfg.decoder_num_heads,
+                              cfg.stage_dims() + cfg.stage_dims()[::-1]):
+            if dim != heads * 64:
+                raise NotImplementedError(
+                    f"the window-attention kernel is built for head_dim 64 (dim {dim}, {heads} heads)"
+                )
+        if int(np.prod(cfg.window_size)) > 144:
+            raise NotImplementedError("windows of more than 144 tokens are not supported")
+        self._sd = {k: v.detach() for k, v in model.state_dict().items()}
+        self._param_stamp = self._stamp()
+        self._grid_cache: dict = {}
+        self._level_cache: dict = {}
+        self._table_cache: dict = {}
+        self._ws_cache: dict = {}
+        self._embed_w_cache: dict = {}
+        self._stat_cache: dict = {}
+        self._lora_sets: "OrderedDict[object, dict]" = OrderedDict()
+        self._pack_static()
+
+    # ---------------------------------------------------------------------------------------
+    # helpers
+    # ---------------------------------------------------------------------------------------
+    def _stamp(self) -> int:
+        return sum(p._version for p in self.model.parameters())
+
+    def is_stale(self) -> bool:
+        return self._stamp() != self._param_stamp
+
+    def empty(self, *shape: int, dtype=F32) -> torch.Tensor:
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _dev(self, arr: np.ndarray) -> torch.Tensor:
+        return torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+
+    def _p(self, name: str) -> torch.Tensor:
+        return self._sd[name].contiguous()
+
+    def _to_bb(self, w: torch.Tensor) -> torch.Tensor:
+        """A weight in the backbone compute dtype (bf16 copy via the HIP convert kernel)."""
+        w = w.contiguous()
+        if self.bb_dtype == F32:
+            return w
+        return lib.convert(w, torch.empty_like(w, dtype=BF16))
+
+    def _linear_new(self, a, w, bias, n_out, **kw) -> torch.Tensor:
+        out = self.empty(a.shape[0], n_out, dtype=a.dtype)
+        return lib.linear(a, w, bias, out, **kw)
+
+    # ---------------------------------------------------------------------------------------
+    # packing (input independent)
+    # ---------------------------------------------------------------------------------------
+    def _pack_static(self) -> None:
+        cfg, sd = self.cfg, self._sd
+        D = cfg.embed_dim
+        hours = cfg.timestep / timedelta(hours=1)
+        lead = self._dev(encodings.lead_time(hours, D)[None])  # (1, D) fp32
+
+        # -- AdaLN modulation of every block: one GEMM over the stacked modulation weights --
+        t1 = self._linear_new(lead, self._p("backbone.time_mlp.0.weight"), self._p("backbone.time_mlp.0.bias"),
+                              D, act=lib.ACT_SILU)
+        silu_c = self._linear_new(t1, self._p("backbone.time_mlp.2.weight"), self._p("backbone.time_mlp.2.bias"),
+                                  D, act=lib.ACT_SILU)  # SiLU(c): the only way c is ever used
+        self.blocks = self._block_list()
+        names = [f"{blk['prefix']}.{n}.ln_modulation.1" for blk in self.blocks for n in ("norm1", "norm2")]
+        w_all = torch.cat([sd[f"{n}.weight"] for n in names], dim=0).contiguous()
+        b_all = torch.cat([sd[f"{n}.bias"] for n in names], dim=0).contiguous()
+        mod = self._linear_new(silu_c, w_all, b_all, w_all.shape[0])[0]
+        off = 0
+        for blk in self.blocks:
+            dim = blk["dim"]
+            for n in ("norm1", "norm2"):
+                # chunk(2): shift first, then scale (film.py:48); scale_bias is 0 in every config.
+                blk[f"{n}.shift"] = mod[off:off + dim]
+                blk[f"{n}.gain"] = mod[off + dim:off + 2 * dim]
+                off += 2 * dim
+
+        # -- backbone weights in the compute dtype --
+        for blk in self.blocks:
+            pre = blk["prefix"]
+            blk["fc1.w"], blk["fc1.b"] = self._to_bb(sd[f"{pre}.mlp.fc1.weight"]), self._p(f"{pre}.mlp.fc1.bias")
+            blk["fc2.w"], blk["fc2.b"] = self._to_bb(sd[f"{pre}.mlp.fc2.weight"]), self._p(f"{pre}.mlp.fc2.bias")
+            blk["qkv.b"], blk["proj.b"] = self._p(f"{pre}.attn.qkv.bias"), self._p(f"{pre}.attn.proj.bias")
+        self._lora_sets["base"] = {
+            blk["prefix"]: (self._to_bb(sd[f"{blk['prefix']}.attn.qkv.weight"]),
+                            self._to_bb(sd[f"{blk['prefix']}.attn.proj.weight"]))
+            for blk in self.blocks
+        }
+        self.merges, self.splits = {}, {}
+        n_enc, n_dec = len(cfg.encoder_depths), len(cfg.decoder_depths)
+        for i in range(n_enc - 1):
+            pre = f"backbone.encoder_layers.{i}.downsample"
+            self.merges[i] = dict(w=self._to_bb(sd[f"{pre}.reduction.weight"]),
+                                  ln_w=self._p(f"{pre}.norm.weight"), ln_b=self._p(f"{pre}.norm.bias"))
+        for i in range(n_dec - 1):
+            pre = f"backbone.decoder_layers.{i}.upsample"
+            self.splits[i] = dict(w1=self._to_bb(sd[f"{pre}.lin1.weight"]), w2=self._to_bb(sd[f"{pre}.lin2.weight"]),
+                                  ln_w=self._p(f"{pre}.norm.weight"), ln_b=self._p(f"{pre}.norm.bias"))
+
+        # -- encoder / decoder constants that depend on parameters only --
+        self.lead_emb = self._linear_new(lead, self._p("encoder.lead_time_embed.weight"),
+                                         self._p("encoder.lead_time_embed.bias"), D)  # (1, D)
+        self.enc_layers = self._pack_resampler("encoder.level_agg", cfg.enc_depth, cfg.num_heads)
+        latents = self._p("encoder.atmos_latents")
+        l0 = self.enc_layers[0]
+        q0 = self._linear_new(latents, l0["to_q"], None, l0["to_q"].shape[0])
+        if "ln_q.w" in l0:
+            lib.layernorm(q0, l0["ln_q.w"], l0["ln_q.b"], out_f32=q0)
+        self.enc_latents, self.enc_q0 = latents, q0
+        self.dec_layers = {"main": self._pack_resampler("decoder.level_decoder", cfg.dec_depth, cfg.num_heads)}
+        if cfg.dec_separate_perceiver:
+            self.dec_layers["alt"] = self._pack_resampler("decoder.level_decoder_alternate", cfg.dec_depth,
+                                                          cfg.num_heads)
+        torch.cuda.current_stream().synchronize()
+
+    def _pack_resampler(self, prefix: str, depth: int, heads: int) -> list[dict]:
+        layers = []
+        for i in range(depth):
+            p = f"{prefix}.layers.{i}"
+            d = dict(to_q=self._p(f"{p}.0.to_q.weight"), to_kv=self._p(f"{p}.0.to_kv.weight"),
+                     to_out=self._p(f"{p}.0.to_out.weight"),
+                     fc1_w=self._p(f"{p}.1.net.0.weight"), fc1_b=self._p(f"{p}.1.net.0.bias"),
+                     fc2_w=self._p(f"{p}.1.net.2.weight"), fc2_b=self._p(f"{p}.1.net.2.bias"),
+                     ln1_w=self._p(f"{p}.2.weight"), ln1_b=self._p(f"{p}.2.bias"),
+                     ln2_w=self._p(f"{p}.3.weight"), ln2_b=self._p(f"{p}.3.bias"))
+            if f"{p}.0.ln_k.weight" in self._sd:
+                d.update({"ln_k.w": self._p(f"{p}.0.ln_k.weight"), "ln_k.b": self._p(f"{p}.0.ln_k.bias"),
+                          "ln_q.w": self._p(f"{p}.0.ln_q.weight"), "ln_q.b": self._p(f"{p}.0.ln_q.bias")})
+            d["inner"] = d["to_q"].shape[0]
+            d["head_dim"] = d["inner"] // heads
+            layers.append(d)
+        return layers
+
+    def _block_list(self) -> list[dict]:
+        cfg = self.cfg
+        dims = cfg.stage_dims()
+        n_dec = len(cfg.decoder_depths)
+        blocks = []
+        for i, depth in enumerate(cfg.encoder_depths):
+            for j in range(depth):
+                blocks.append(dict(prefix=f"backbone.encoder_layers.{i}.blocks.{j}", dim=dims[i], stage=i,
+                                   heads=cfg.encoder_num_heads[i], shifted=j % 2 == 1, part="enc", layer=i, j=j))
+        for i, depth in enumerate(cfg.decoder_depths):
+            s = n_dec - 1 - i
+            for j in range(depth):
+                blocks.append(dict(prefix=f"backbone.decoder_layers.{i}.blocks.{j}", dim=dims[s], stage=s,
+                                   heads=cfg.decoder_num_heads[i], shifted=j % 2 == 1, part="dec", layer=i, j=j))
+        return blocks
+
+    # -- LoRA weight sets ---------------------------------------------------------------------
+    def _lora_key(self, step: int):
+        """Which merged weight set roll-out step `step` uses (reference lora.py:105-129)."""
+        cfg = self.cfg
+        if not cfg.use_lora or step >= cfg.lora_steps:
+            return "base"
+        if cfg.lora_mode == "single":
+            return 0
+        if cfg.lora_mode == "from_second":
+            return "base" if step == 0 else 0
+        if cfg.lora_mode == "all":
+            return step
+        raise ValueError(f"Invalid mode: {cfg.lora_mode}")
+
+    def _attn_weights(self, step: int) -> dict:
+        key = self._lora_key(step)
+        if key not in self._lora_sets:
+            sd, out = self._sd, {}
+            scaling = LORA_ALPHA / LORA_RANK
+            assert scaling == 1.0
+            for blk in self.blocks:
+                pre = blk["prefix"]
+                pair = []
+                for which in ("qkv", "proj"):
+                    w = sd[f"{pre}.attn.{which}.weight"].contiguous()
+                    a = sd[f"{pre}.attn.lora_{which}.loras.{key}.lora_A"]  # (r, in)
+                    b = sd[f"{pre}.attn.lora_{which}.loras.{key}.lora_B"]  # (out, r)
+                    # W' = W + B A: a rank-8 GEMM (K zero-padded to one 32-wide fp32 K-tile) with the
+                    # base weight as residual -- LoRA costs nothing per step afterwards.
+                    a_t = torch.zeros((a.shape[1], 32), dtype=F32, device=self.device)
+                    a_t[:, :LORA_RANK] = a.t()
+                    b_p = torch.zeros((b.shape[0], 32), dtype=F32, device=self.device)
+                    b_p[:, :LORA_RANK] = b
+                    merged = lib.linear(b_p, a_t, None, torch.empty_like(w), residual=w)
+                    pair.append(self._to_bb(merged))
+                out[pre] = tuple(pair)
+            self._lora_sets[key] = out
+            while len(self._lora_sets) > 4:  # "all" mode: keep base + the most recent sets
+                for k in self._lora_sets:
+                    if k != "base" and k != key:
+                        del self._lora_sets[k]
+                        break
+        return self._lora_sets[key]
+
+    # -- per grid / per level-set constants -----------------------------------------------------
+    def _grid(self, lat: torch.Tensor, lon: torch.Tensor) -> torch.Tensor:
+        """pos_embed(pos) + scale_embed(scale) of the patch grid, (L, D) fp32, cached.
+
+        Looked up by tensor identity first (a roll-out passes the same lat/lon objects from step
+        to step, so no device->host copy happens per step), then by content.
+        """
+        ident = (id(lat), id(lon), lat._version, lon._version)
+        hit = self._grid_cache.get("ident")
+        if hit is not None and hit[0] == ident:
+            return hit[3]
+        lat_h, lon_h = lat.detach().cpu(), lon.detach().cpu()
+        key = (tuple(lat_h.shape), tuple(lon_h.shape), lat_h.numpy().tobytes(), lon_h.numpy().tobytes())
+        if key not in self._grid_cache:
+            D, P = self.cfg.embed_dim, self.cfg.patch_size
+            pos, scale = encodings.pos_scale_encodings(D, lat_h, lon_h, P)
+            pe = self._linear_new(self._dev(pos), self._p("encoder.pos_embed.weight"),
+                                  self._p("encoder.pos_embed.bias"), D)
+            ps = lib.linear(self._dev(scale), self._p("encoder.scale_embed.weight"),
+                            self._p("encoder.scale_embed.bias"), torch.empty_like(pe), residual=pe)
+            if len(self._grid_cache) > 8:
+                self._grid_cache.clear()
+            self._grid_cache[key] = ps
+        self._grid_cache["ident"] = (ident, lat, lon, self._grid_cache[key])  # holds lat/lon alive
+        return self._grid_cache[key]
+
+    def _levels(self, levels: tuple) -> dict:
+        if levels not in self._level_cache:
+            cfg = self.cfg
+            D, D2 = cfg.embed_dim, 2 * cfg.embed_dim
+            C = len(levels)
+            enc = self._dev(encodings.levels(levels, D))
+            # per-level bias of the atmospheric patch embedding: patch bias + level embedding
+            if cfg.level_condition:
+                pb = torch.stack([self._p(f"encoder.atmos_token_embeds.layers.{level_to_str(lv)}.bias")
+                                  for lv in levels])
+                bias = lib.linear(enc, self._p("encoder.atmos_levels_embed.weight"),
+                                  self._p("encoder.atmos_levels_embed.bias"), self.empty(C, D), residual=pb)
+            else:
+                pb = self._p("encoder.atmos_token_embeds.bias")[None].expand(C, D)
+                bias = lib.linear(enc, self._p("encoder.atmos_levels_embed.weight"),
+                                  self._p("encoder.atmos_levels_embed.bias"), self.empty(C, D), residual=pb)
+            dec = self._dev(encodings.levels(levels, D2))
+            queries = self._linear_new(dec, self._p("decoder.atmos_levels_embed.weight"),
+                                       self._p("decoder.atmos_levels_embed.bias"), D2)
+            out = dict(enc_bias=bias, dec_queries=queries)
+            for name, layers in self.dec_layers.items():
+                out[f"dec_q.{name}"] = self._linear_new(queries, layers[0]["to_q"], None, layers[0]["inner"])
+            self._level_cache[levels] = out
+        return self._level_cache[levels]
+
+    def _tables(self, res, shifted: bool):
+        key = (res, shifted)
+        if key not in self._table_cache:
+            tok, grp, _ = geometry.window_tables(tuple(res), tuple(self.cfg.window_size), shifted)
+            self._table_cache[key] = (self._dev(tok), None if grp is None else self._dev(grp))
+        return self._table_cache[key]
+
+    def _stats(self, kind: str, name: str, levels: tuple):
+        """Device (loc, scale, 1/scale) vectors of a variable, refreshed when the tables change."""
+        if kind == "surf":
+            loc, sc = normalisation.surf_affine(name, self.model.surf_stats)
+            locs, scs = [loc], [sc]
+        elif kind == "one":  # constant planes (dynamic variables): identity normalisation
+            locs, scs = [0.0], [1.0]
+        else:
+            locs, scs = normalisation.atmos_affine(name, levels)
+        key = (kind, name, levels)
+        val = (tuple(locs), tuple(scs))
+        hit = self._stat_cache.get(key)
+        if hit is None or hit[0] != val:
+            loc_t = torch.tensor(locs, dtype=F32, device=self.device)
+            sc_t = torch.tensor(scs, dtype=F32, device=self.device)
+            inv_t = torch.tensor([1.0 / s for s in scs], dtype=torch.float64).to(F32).to(self.device)
+            hit = (val, loc_t, sc_t, inv_t)
+            self._stat_cache[key] = hit
+        return hit[1], hit[2], hit[3]
+
+    def _embed_weight(self, prefix: str, names: tuple, T: int) -> tuple[torch.Tensor, int]:
+        """(D, Kpad) GEMM weight of a LevelPatchEmbed for the given variable order / history."""
+        key = (prefix, names, T)
+        if key not in self._embed_w_cache:
+            ws = [self._sd[f"{prefix}.weights.{n}"][:, 0, :T] for n in names]  # (D, T, P, P) each
+            w = torch.stack(ws, dim=1).reshape(ws[0].shape[0], -1)  # (D, V*T*P*P), (v, t, i, j) order
+            K = w.shape[1]
+            Kpad = _round_up(K, 32)
+            wp = torch.zeros((w.shape[0], Kpad), dtype=F32, device=self.device)
+            wp[:, :K] = w
+            self._embed_w_cache[key] = (wp, K)
+        return self._embed_w_cache[key]
+
+    # ---------------------------------------------------------------------------------------
+    # the step
+    # ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, batch: Batch) -> Batch:
+        model, cfg = self.model, self.cfg
+        if self.is_stale():
+            raise RuntimeError("model parameters changed after packing: call model._engine = None first")
+        batch = model.batch_transform_hook(batch)
+        batch = batch.type(F32).crop(cfg.patch_size).to(self.device)
+        md = batch.metadata
+        levels = tuple(md.atmos_levels)
+        P, D = cfg.patch_size, cfg.embed_dim
+        H, W = batch.spatial_shape
+        Hp, Wp = H // P, W // P
+        L = Hp * Wp
+        patch_res = (cfg.latent_levels, Hp, Wp)
+        B, T = next(iter(batch.surf_vars.values())).shape[:2]
+        assert T <= cfg.max_history_size, f"{T} > {cfg.max_history_size}."
+        assert md.lat.shape[0] == H and md.lon.shape[-1] == W
+        assert md.lat.dtype in (torch.float32, torch.float64), f"Latitude num. unstable: {md.lat.dtype}."
+        assert md.lon.dtype in (torch.float32, torch.float64), f"Longitude num. unstable: {md.lon.dtype}."
+        assert cfg.latent_levels % cfg.window_size[0] == 0, "latent levels must be divisible by ws[0]"
+
+        x_f, x_b = self._encode(batch, B, T, H, W, Hp, Wp, levels)
+        x_cat = self._backbone(x_f, x_b, B, patch_res, md.rollout_step)
+        return self._decode(x_cat, batch, B, H, W, Hp, Wp, levels)
+
+    # -- encoder ------------------------------------------------------------------------------
+    def _var_desc(self, t: torch.Tensor, kind: str, name: str, levels: tuple, transform=0, comb=None) -> lib.PatchVar:
+        loc, _, inv = self._stats(kind, name, levels)
+        if kind == "surf" and t.dim() == 2:      # static (H, W)
+            sb = st = sc = 0
+            sh, sw = t.stride()
+        elif kind == "surf":                      # (B, T, H, W)
+            sb, st, sh, sw = t.stride()
+            sc = 0
+        elif kind == "one":                       # (B,) constant plane per batch element
+            sb, st, sc, sh, sw = t.stride(0), 0, 0, 0, 0
+        elif t.dim() == 2:                        # static fed at every level
+            sb = st = sc = 0
+            sh, sw = t.stride()
+        elif t.dim() == 1:                        # constant plane fed at every level
+            sb, st, sc, sh, sw = t.stride(0), 0, 0, 0, 0
+        else:                                     # (B, T, C, H, W)
+            sb, st, sc, sh, sw = t.stride()
+        tw0 = tw1 = tb = 0.0
+        if comb is not None:
+            tw0, tw1, tb = comb
+        return lib.PatchVar(t.data_ptr(), sb, st, sc, sh, sw, loc.data_ptr(), inv.data_ptr(), transform, tw0, tw1, tb)
+
+    def _combiner(self, kind: str, name: str):
+        w = self._sd[f"{kind}_feature_combiner.{name}.weight"].reshape(-1).tolist()
+        b = self._sd[f"{kind}_feature_combiner.{name}.bias"].reshape(-1).tolist()
+        return (w[0], w[1], b[0])
+
+    def _encode(self, batch: Batch, B, T, H, W, Hp, Wp, levels):
+        cfg, model = self.cfg, self.model
+        P, D = cfg.patch_size, cfg.embed_dim
+        L, C = Hp * Wp, len(levels)
+        keep = []  # tensors whose storage must outlive the enqueued kernels of this call
+
+        def transform_of(kind, name):
+            pos = cfg.positive_surf_vars if kind == "surf" else cfg.positive_atmos_vars
+            if name not in pos:
+                return 0, None
+            if model.variant == "air_pollution":
+                return 2, self._combiner(kind, name)
+            return 1, None
+
+        f32c = lambda t: t if t.dtype == F32 else t.to(F32)  # noqa: E731
+        surf = {k: f32c(v) for k, v in batch.surf_vars.items()}
+        static = {k: f32c(v) for k, v in batch.static_vars.items()}
+        atmos = {k: f32c(v) for k, v in batch.atmos_vars.items()}
+        keep += list(surf.values()) + list(static.values()) + list(atmos.values())
+
+        surf_names = tuple(surf) + tuple(static)
+        descs = [self._var_desc(v, "surf", k, levels, *transform_of("surf", k)) for k, v in surf.items()]
+        descs += [self._var_desc(v, "surf", k, levels) for k, v in static.items()]
+        dyn_t = []
+        if cfg.dynamic_vars:
+            times = batch.metadata.time
+            vals = np.array([[np.cos(2 * np.pi * t.hour / 24), np.sin(2 * np.pi * t.hour / 24),
+                              np.cos(2 * np.pi * t.weekday() / 7), np.sin(2 * np.pi * t.weekday() / 7),
+                              np.cos(2 * np.pi * t.day / 365.25), np.sin(2 * np.pi * t.day / 365.25)]
+                             for t in times], dtype=np.float64).astype(np.float32)  # (B, 6)
+            dyn = self._dev(vals.T.copy())  # (6, B)
+            keep.append(dyn)
+            dyn_t = [dyn[i] for i in range(6)]
+            surf_names += DYNAMIC_VARS
+            descs += [self._var_desc(t, "one", n, levels) for n, t in zip(DYNAMIC_VARS, dyn_t)]
+
+        atmos_names = tuple(atmos)
+        adescs = [self._var_desc(v, "atmos", k, levels, *transform_of("atmos", k)) for k, v in atmos.items()]
+        if cfg.atmos_static_vars:
+            if cfg.dynamic_vars:
+                extra = list(static.items()) + list(zip(DYNAMIC_VARS, dyn_t))
+                atmos_names += tuple(f"static_{n}" for n, _ in extra)
+            else:  # the reference appends the bare static names here (encoder.py:268-269)
+                extra = list(static.items())
+                atmos_names += tuple(n for n, _ in extra)
+            for n, t in extra:
+                kind = "one" if t.dim() == 1 else "surf"
+                d = self._var_desc(t, kind, n, levels)
+                if kind == "surf":  # static plane normalised with its surface statistics, every level
+                    loc, _, inv = self._stats("surf", n, levels)
+                    loc_c, inv_c = loc.expand(C).contiguous(), inv.expand(C).contiguous()
+                    keep += [loc_c, inv_c]
+                    d.loc, d.inv_scale = loc_c.data_ptr(), inv_c.data_ptr()
+                else:
+                    loc, _, inv = self._stats("one", n, levels)
+                    loc_c, inv_c = loc.expand(C).contiguous(), inv.expand(C).contiguous()
+                    keep += [loc_c, inv_c]
+                    d.loc, d.inv_scale = loc_c.data_ptr(), inv_c.data_ptr()
+                adescs.append(d)
+        if cfg.simulate_indexing_bug and "z" in atmos_names:
+            # the slot of `static_z` is fed with `z`'s data (encoder.py:293-303)
+            adescs[atmos_names.index("static_z")] = adescs[atmos_names.index("z")]
+
+        # ---- surface level ----
+        w_s, K_s = self._embed_weight("encoder.surf_token_embeds", surf_names, T)
+        A_s = self.empty(B * L, w_s.shape[1])
+        for i in range(0, len(descs), 32):
+            lib.patchify(descs[i:i + 32], A_s, i * T * P * P, K_s, B, T, 1, Hp, Wp, P)
+        sle = self._p("encoder.surf_level_encoding")[None].expand(B * L, D)  # stride-0 residual rows
+        xs0 = lib.linear(A_s, w_s, self._p("encoder.surf_token_embeds.bias"), self.empty(B * L, D), residual=sle)
+        hid = self._linear_new(xs0, self._p("encoder.surf_mlp.net.0.weight"), self._p("encoder.surf_mlp.net.0.bias"),
+                               self._sd["encoder.surf_mlp.net.0.weight"].shape[0], act=lib.ACT_GELU)
+        y = self._linear_new(hid, self._p("encoder.surf_mlp.net.2.weight"), self._p("encoder.surf_mlp.net.2.bias"), D)
+        xs1 = self.empty(B * L, D)
+        lib.layernorm(y, self._p("encoder.surf_norm.weight"), self._p("encoder.surf_norm.bias"), res=xs0, out_f32=xs1)
+        del hid, y, A_s
+
+        # ---- atmospheric levels ----
+        lv = self._levels(levels)
+        if cfg.level_condition:
+            packs = [self._embed_weight(f"encoder.atmos_token_embeds.layers.{level_to_str(l_)}", atmos_names, T)
+                     for l_ in levels]
+        else:
+            packs = [self._embed_weight("encoder.atmos_token_embeds", atmos_names, T)] * C
+        K_a = packs[0][1]
+        A_a = self.empty(C * B * L, packs[0][0].shape[1])
+        for i in range(0, len(adescs), 32):
+            lib.patchify(adescs[i:i + 32], A_a, i * T * P * P, K_a, B, T, C, Hp, Wp, P)
+        xa = self.empty(C * B * L, D)
+        R = B * L
+        for c in range(C):
+            lib.linear(A_a[c * R:(c + 1) * R], packs[c][0], lv["enc_bias"][c], xa[c * R:(c + 1) * R])
+        del A_a
+
+        # ---- level aggregation (Perceiver resampler over the level axis) ----
+        n_lat = cfg.latent_levels - 1
+        lat = self._resampler(self.enc_layers, xa, q0=self.enc_q0, latents0=self.enc_latents, B=B, cols=L,
+                              kv_bstride=L, kv_lstride=B * L, Lq=n_lat, Lk=C, heads=cfg.num_heads,
+                              eps=cfg.perceiver_ln_eps)
+        del xa
+
+        # ---- assemble tokens + position / scale / time embeddings ----
+        pos_scale = self._grid(batch.metadata.lat, batch.metadata.lon)
+        stamps = [t.timestamp() / 3600 for t in batch.metadata.time]
+        abs_enc = self._dev(encodings.absolute_time(stamps, D))
+        time_emb = lib.linear(abs_enc, self._p("encoder.absolute_time_embed.weight"),
+                              self._p("encoder.absolute_time_embed.bias"), self.empty(B, D),
+                              residual=self.lead_emb.expand(B, D))
+        Cl = cfg.latent_levels
+        x_f = self.empty(B * Cl * L, D)
+        x_b = self.empty(B * Cl * L, D, dtype=BF16) if self.bb_dtype == BF16 else None
+        lib.assemble_tokens(xs1, lat, pos_scale, time_emb, x_f, x_b, B, Cl, L, D)
+        self._keepalive = keep
+        return x_f, x_b
+
+    def _resampler(self, layers, ctx, *, q0, latents0, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, eps):
+        """PerceiverResampler (perceiver.py:212-233) for all grid columns at once.
+
+        ctx: context rows, key j of column (b, l) at row b*kv_bstride + j*kv_lstride + l.
+        First layer: the latents (and so q) are the same for every column.  Returns (B*cols*Lq, D).
+        """
+        lat = None
+        n_rows = B * cols * Lq
+        for i, ly in enumerate(layers):
+            inner, hd = ly["inner"], ly["head_dim"]
+            kv = self._linear_new(ctx, ly["to_kv"], None, 2 * inner)
+            if "ln_k.w" in ly:  # LayerNorm over the K half, in place (perceiver.py:144-147)
+                lib.layernorm(kv, ly["ln_k.w"], ly["ln_k.b"], out_f32=kv, d=inner)
+            if i == 0:
+                q, q_stride = q0, 0
+            else:
+                q = self._linear_new(lat, ly["to_q"], None, inner)
+                if "ln_q.w" in ly:
+                    lib.layernorm(q, ly["ln_q.w"], ly["ln_q.b"], out_f32=q)
+                q_stride = Lq
+            att = lib.perceiver_attention(q, q_stride, kv, self.empty(n_rows, inner), B, cols, kv_bstride,
+                                          kv_lstride, Lq, Lk, heads, hd)
+            del kv
+            D = ly["to_out"].shape[0]
+            o = self._linear_new(att, ly["to_out"], None, D)
+            del att
+            lat1 = self.empty(n_rows, D)
+            if i == 0:
+                lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], res=latents0, res_mod=Lq, out_f32=lat1, eps=eps)
+            else:
+                lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], res=lat, out_f32=lat1, eps=eps)
+            del o
+            hid = self._linear_new(lat1, ly["fc1_w"], ly["fc1_b"], ly["fc1_w"].shape[0], act=lib.ACT_GELU)
+            y = self._linear_new(hid, ly["fc2_w"], ly["fc2_b"], D)
+            del hid
+            lib.layernorm(y, ly["ln2_w"], ly["ln2_b"], res=lat1, out_f32=y, eps=eps)
+            lat = y
+        return lat
+
+    # -- backbone -----------------------------------------------------------------------------
+    def _backbone(self, x_f, x_b, B, patch_res, rollout_step: int):
+        cfg = self.cfg
+        bf = self.bb_dtype == BF16
+        T_ = self.bb_dtype
+        n_enc, n_dec = len(cfg.encoder_depths), len(cfg.decoder_depths)
+        all_res, pads = geometry.stage_resolutions(patch_res, n_enc)
+        attn_w = self._attn_weights(rollout_step)
+        dims = cfg.stage_dims()
+
+        def run_blocks(blocks, x_f, x_b, res, final_out=None):
+            C, H, W = res
+            Ls = C * H * W
+            M = B * Ls
+            for bi, blk in enumerate(blocks):
+                dim, heads = blk["dim"], blk["heads"]
+                a_in = x_b if bf else x_f
+                w_qkv, w_proj = attn_w[blk["prefix"]]
+                qkv = lib.linear(a_in, w_qkv, blk["qkv.b"], self.empty(M, 3 * dim, dtype=T_))
+                tok, grp = self._tables(res, blk["shifted"])
+                ao = lib.window_attention(qkv, blk["qkv.b"], self.empty(M, dim, dtype=T_), tok, grp, B, Ls, dim, heads)
+                del qkv
+                y = lib.linear(ao, w_proj, blk["proj.b"], self.empty(M, dim, dtype=T_))
+                del ao
+                lib.layernorm(y, blk["norm1.gain"], blk["norm1.shift"], res=x_f, out_f32=x_f, out_t=x_b)
+                del y
+                hid = lib.linear(a_in, blk["fc1.w"], blk["fc1.b"], self.empty(M, blk["fc1.w"].shape[0], dtype=T_),
+                                 act=lib.ACT_GELU)
+                y = lib.linear(hid, blk["fc2.w"], blk["fc2.b"], self.empty(M, dim, dtype=T_))
+                del hid
+                last = final_out is not None and bi == len(blocks) - 1
+                lib.layernorm(y, blk["norm2.gain"], blk["norm2.shift"], res=x_f,
+                              out_f32=final_out if last else x_f, out_t=None if last else x_b)
+                del y
+            return x_f, x_b
+
+        by_layer = lambda part, i: [b for b in self.blocks if b["part"] == part and b["layer"] == i]  # noqa: E731
+
+        skips = []
+        for i in range(n_enc):
+            x_f, x_b = run_blocks(by_layer("enc", i), x_f, x_b, all_res[i])
+            skips.append(x_f)
+            if i < n_enc - 1:
+                C, H, W = all_res[i]
+                m = self.merges[i]
+                H2, W2 = (H + 1) // 2, (W + 1) // 2
+                M2 = B * C * H2 * W2
+                mg = lib.merge_ln(x_f, m["ln_w"], m["ln_b"], self.empty(M2, 4 * dims[i], dtype=T_), B, C, H, W, dims[i])
+                nf = self.empty(M2, dims[i + 1])
+                if bf:
+                    nb = self.empty(M2, dims[i + 1], dtype=BF16)
+                    lib.linear(mg, m["w"], None, nb, out2=nf)
+                else:
+                    nb = None
+                    lib.linear(mg, m["w"], None, nf)
+                del mg
+                x_f, x_b = nf, nb
+
+        D0 = dims[0]
+        L0 = int(np.prod(all_res[0]))
+        x_cat = self.empty(B * L0, 2 * D0)
+        for i in range(n_dec):
+            idx = n_dec - 1 - i
+            last_layer = i == n_dec - 1
+            final_out = x_cat[:, :D0] if last_layer else None
+            blocks = by_layer("dec", i)
+            x_f, x_b = run_blocks(blocks, x_f, x_b, all_res[idx], final_out=final_out)
+            if last_layer and not blocks:
+                lib.copy2d(x_f, x_cat[:, :D0])
+            if i < n_dec - 1:
+                C, H, W = all_res[idx]
+                s = self.splits[i]
+                dim = dims[idx]
+                a_in = x_b if bf else x_f
+                y1 = lib.linear(a_in, s["w1"], None, self.empty(B * C * H * W, 2 * dim, dtype=T_))
+                crop = pads[idx - 1]
+                Ho, Wo = 2 * H - crop[1], 2 * W - crop[2]
+                assert (C, Ho, Wo) == tuple(all_res[idx - 1])
+                M2 = B * C * Ho * Wo
+                sp = lib.split_ln(y1, s["ln_w"], s["ln_b"], self.empty(M2, dim // 2, dtype=T_), B, C, H, W,
+                                  dim // 2, crop[1], crop[2])
+                del y1
+                # additive skip after the intermediate decoder stages (swin3d.py:930-932): the
+                # reference adds skips[index-1] after decoder layer i for 0 < i < n_dec-1, i.e. to
+                # the up-sampled output of layer i.  Layer i's up-sampling is this GEMM.
+                add_skip = 0 < i < n_dec - 1
+                res = skips[idx - 1] if add_skip else None
+                nf = self.empty(M2, dim // 2)
+                if bf:
+                    nb = self.empty(M2, dim // 2, dtype=BF16)
+                    lib.linear(sp, s["w2"], None, nb, out2=nf, residual=res)
+                else:
+                    nb = None
+                    lib.linear(sp, s["w2"], None, nf, residual=res)
+                del sp
+                x_f, x_b = nf, nb
+        lib.copy2d(skips[0], x_cat[:, D0:])
+        return x_cat
+
+    # -- decoder ------------------------------------------------------------------------------
+    def _decode(self, x_cat, batch: Batch, B, H, W, Hp, Wp, levels) -> Batch:
+        cfg, model = self.cfg, self.model
+        P, D2 = cfg.patch_size, 2 * cfg.embed_dim
+        L, Cl, CA = Hp * Wp, cfg.latent_levels, len(levels)
+        md = batch.metadata
+        lv = self._levels(levels)
+        new_step = md.rollout_step + 1
+        clamp_now = new_step >= 1 if cfg.clamp_at_first_step else new_step > 1
+        diff = type(model)._predict_difference_history_dim_lookup if model.variant == "air_pollution" else {}
+
+        surf_in, atmos_in = tuple(batch.surf_vars), tuple(batch.atmos_vars)
+        surf_heads = surf_in + tuple(f"{n}_mod" for n in surf_in if n in cfg.modulation_heads)
+        atmos_heads = atmos_in + tuple(f"{n}_mod" for n in atmos_in if n in cfg.modulation_heads)
+        P2 = P * P
+
+        # ---- surface heads on latent level 0 ----
+        w_sh, b_sh = self._head_weights("surf", surf_heads, levels)
+        n_s = len(surf_heads) * P2
+        ld_s = _round_up(n_s, 4)
+        y_s = self.empty(B * L, ld_s)
+        for b in range(B):
+            lib.linear(x_cat[b * Cl * L:b * Cl * L + L], w_sh, b_sh, y_s[b * L:(b + 1) * L], n=n_s)
+        out_s = self.empty(len(surf_in), B, 1, H, W)
+        descs = []
+        for i, n in enumerate(surf_in):
+            loc, sc, _ = self._stats("surf", n, levels)
+            d = lib.UnpatchVar(out_s[i].data_ptr(), loc.data_ptr(), sc.data_ptr(),
+                               int(clamp_now and n in cfg.positive_surf_vars), surf_heads.index(n) * P2)
+            self._diff_fields(d, n, diff, surf_heads, P2, 0, batch.surf_vars, levels, False)
+            descs.append(d)
+        for i in range(0, len(descs), 32):
+            lib.unpatchify(y_s, descs[i:i + 32], B, 1, Hp, Wp, P)
+
+        # ---- level de-aggregation ----
+        ctx = self.empty(B * (Cl - 1) * L, D2) if B > 1 else None
+        if B == 1:
+            ctx = x_cat[L:Cl * L]
+        else:
+            for b in range(B):
+                lib.copy2d(x_cat[b * Cl * L + L:(b + 1) * Cl * L], ctx[b * (Cl - 1) * L:(b + 1) * (Cl - 1) * L])
+        sep = cfg.dec_separate_perceiver
+        groups = {"main": [n for n in atmos_heads if n not in sep]}
+        if sep:
+            groups["alt"] = [n for n in atmos_heads if n in sep]
+        out_a = self.empty(len(atmos_in), B, CA, H, W)
+        for gname, names in groups.items():
+            if not names:
+                continue
+            lat = self._resampler(self.dec_layers[gname], ctx, q0=lv[f"dec_q.{gname}"], latents0=lv["dec_queries"],
+                                  B=B, cols=L, kv_bstride=(Cl - 1) * L, kv_lstride=L, Lq=CA, Lk=Cl - 1,
+                                  heads=cfg.num_heads, eps=cfg.perceiver_ln_eps)
+            w_ah, b_ah = self._head_weights("atmos", tuple(names), levels)
+            lvl_stride = len(names) * P2 if cfg.level_condition else 0
+            n_a = w_ah.shape[0]
+            y_a = lib.linear(lat, w_ah, b_ah, self.empty(B * L * CA, _round_up(n_a, 4)), n=n_a)
+            del lat
+            descs = []
+            for n in names:
+                if n.endswith("_mod") and n[:-4] in diff:
+                    continue  # consumed by its base variable
+                i = atmos_in.index(n)
+                loc, sc, _ = self._stats("atmos", n, levels)
+                d = lib.UnpatchVar(out_a[i].data_ptr(), loc.data_ptr(), sc.data_ptr(),
+                                   int(clamp_now and n in cfg.positive_atmos_vars), names.index(n) * P2)
+                d.lvl_stride = lvl_stride
+                self._diff_fields(d, n, diff, names, P2, lvl_stride, batch.atmos_vars, levels, True)
+                if model.variant == "air_pollution" and cfg.use_lora and n == "so2":
+                    d.clamp_max1_levels = sum(1 << c for c, l_ in enumerate(levels) if l_ >= 850)
+                descs.append(d)
+            for i in range(0, len(descs), 32):
+                lib.unpatchify(y_a, descs[i:i + 32], B, CA, Hp, Wp, P)
+            self._keep_y = y_a
+
+        surf_out = {n: out_s[i] for i, n in enumerate(surf_in)}               # (B, 1, H, W)
+        atmos_out = {n: out_a[i][:, None] for i, n in enumerate(atmos_in)}    # (B, 1, C, H, W)
+        return Batch(
+            surf_out,
+            dict(batch.static_vars),
+            atmos_out,
+            Metadata(lat=md.lat.to(F32), lon=md.lon.to(F32),
+                     time=tuple(t + cfg.timestep for t in md.time), atmos_levels=md.atmos_levels,
+                     rollout_step=new_step),
+        )
+
+    def _diff_fields(self, d, name, diff, head_names, P2, lvl_stride, prev_vars, levels, is_atmos):
+        """Air-pollution difference prediction (aurora.py:761-779): fields of the descriptor."""
+        if name in diff and f"{name}_mod" in head_names:
+            prev = prev_vars[name]
+            idx = diff[name]
+            d.mod_col0 = head_names.index(f"{name}_mod") * P2
+            pv = prev[:, idx]
+            d.prev = pv.data_ptr()
+            if is_atmos:
+                d.prev_sb, d.prev_sc, d.prev_sh = pv.stride(0), pv.stride(1), pv.stride(2)
+            else:
+                d.prev_sb, d.prev_sc, d.prev_sh = pv.stride(0), 0, pv.stride(1)
+            assert pv.stride(-1) == 1
+            _, _, inv = self._stats("atmos" if is_atmos else "surf", name, levels)
+            d.inv_scale = inv.data_ptr()
+        else:
+            d.mod_col0 = -1
+
+    def _head_weights(self, kind: str, names: tuple, levels: tuple):
+        key = ("head", kind, names, levels if self.cfg.level_condition and kind == "atmos" else None)
+        if key not in self._embed_w_cache:
+            sd = self._sd
+            if kind == "atmos" and self.cfg.level_condition:
+                ws = [sd[f"decoder.atmos_heads.{n}.layers.{level_to_str(lv)}.weight"] for lv in levels for n in names]
+                bs = [sd[f"decoder.atmos_heads.{n}.layers.{level_to_str(lv)}.bias"] for lv in levels for n in names]
+            else:
+                ws = [sd[f"decoder.{kind}_heads.{n}.weight"] for n in names]
+                bs = [sd[f"decoder.{kind}_heads.{n}.bias"] for n in names]
+            self._embed_w_cache[key] = (torch.cat(ws, dim=0).contiguous(), torch.cat(bs, dim=0).contiguous())
+        return self._embed_w_cache[key]

@@ -1,0 +1,266 @@
+"""ctypes binding of libaurora_hip.so (include/aurora_hip.h).
+
+PyTorch is used for device memory and streams only: every wrapper below takes torch CUDA
+(HIP) tensors, checks what the C ABI cannot check (device, dtype, contiguity of the inner
+dimension) and passes raw device pointers plus the current HIP stream.  A missing library is a
+hard error -- there is no fallback implementation in this package.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int, c_int32, c_int64, c_void_p
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+
+_LIB_PATH = Path(__file__).resolve().parents[1] / "_lib" / "libaurora_hip.so"
+
+
+class PatchVar(ctypes.Structure):
+    _fields_ = [
+        ("src", c_void_p), ("stride_b", c_int64), ("stride_t", c_int64), ("stride_c", c_int64),
+        ("stride_h", c_int64), ("stride_w", c_int64), ("loc", c_void_p), ("inv_scale", c_void_p),
+        ("transform", c_int32), ("tw0", c_float), ("tw1", c_float), ("tb", c_float),
+    ]
+
+
+class UnpatchVar(ctypes.Structure):
+    _fields_ = [("dst", c_void_p), ("loc", c_void_p), ("scale", c_void_p),
+                ("clamp_min0", c_int32), ("col0", c_int32), ("lvl_stride", c_int32), ("mod_col0", c_int32),
+                ("prev", c_void_p), ("prev_sb", c_int64), ("prev_sc", c_int64), ("prev_sh", c_int64),
+                ("inv_scale", c_void_p), ("clamp_max1_levels", ctypes.c_uint32)]
+
+
+_SIGNATURES = {
+    "aurora_hip_version": (c_int, []),
+    "aurora_hip_last_error": (ctypes.c_char_p, []),
+    "aurora_hip_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                  c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                  c_int, c_void_p]),
+    "aurora_hip_window_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                            c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "aurora_hip_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                     c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float,
+                                     c_int, c_void_p]),
+    "aurora_hip_merge_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_int, c_float, c_int, c_void_p]),
+    "aurora_hip_split_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "aurora_hip_patchify": (c_int, [ctypes.POINTER(PatchVar), c_int, c_void_p, c_int64, c_int, c_int,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "aurora_hip_perceiver_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64,
+                                               c_int64, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                               c_void_p]),
+    "aurora_hip_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int64, c_int, c_int, c_void_p]),
+    "aurora_hip_unpatchify": (c_int, [c_void_p, c_int64, ctypes.POINTER(UnpatchVar), c_int, c_int,
+                                      c_int, c_int, c_int, c_int, c_void_p]),
+    "aurora_hip_copy2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                  c_void_p]),
+    "aurora_hip_convert": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library once; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build it with `python -m aurora_amd.build` "
+                "(hipcc, gfx950). aurora_amd has no fallback compute path."
+            )
+        lib = ctypes.CDLL(str(_LIB_PATH))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _check(code: int) -> None:
+    if code != 0:
+        msg = load().aurora_hip_last_error().decode(errors="replace")
+        # -1 = AURORA_E_ARG: the Python shim re-raises argument violations as the assertion /
+        # value errors the reference raises for bad shapes.
+        raise (ValueError if code == -1 else HipError)(f"libaurora_hip: {msg} (code {code})")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported compute dtype {dt}: the HIP engine computes in fp32 or bf16")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda, "tensor must live on the HIP device"
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows(t: torch.Tensor) -> tuple[int, int]:
+    """(leading dimension in elements, inner size) of a 2-D view with unit inner stride."""
+    assert t.dim() == 2 and t.stride(1) == 1, f"need a row-major 2-D view, got {t.shape} / {t.stride()}"
+    return t.stride(0), t.shape[1]
+
+
+# ---- wrappers ------------------------------------------------------------------------------
+def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
+           out2: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           act: int = ACT_NONE, n: Optional[int] = None, k: Optional[int] = None) -> torch.Tensor:
+    """out[M, N] = act(a[M, K] @ w[N, K].T + bias) (+ residual); all 2-D row-major views."""
+    lda, ka = _rows(a)
+    ldw, kw = _rows(w)
+    K = k if k is not None else ka
+    N = n if n is not None else w.shape[0]
+    M = a.shape[0]
+    assert kw >= K and ka >= K and a.dtype == w.dtype == out.dtype, (a.dtype, w.dtype, out.dtype)
+    assert out.shape[0] == M and out.shape[1] >= N
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() >= N and bias.is_contiguous())
+    ldc, _ = _rows(out)
+    ldc2 = ldr = 0
+    if out2 is not None:
+        assert out2.dtype != out.dtype and out2.shape[0] == M
+        ldc2, _ = _rows(out2)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.shape[0] == M
+        ldr, _ = _rows(residual)
+    _check(load().aurora_hip_linear(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), _ptr(out), ldc, _ptr(out2),
+                                    ldc2, _ptr(residual), ldr, M, N, K, dtype_code(a.dtype), act,
+                                    _stream()))
+    return out
+
+
+def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], out: torch.Tensor,
+                     tok: torch.Tensor, grp: Optional[torch.Tensor], B: int, L: int, D: int,
+                     heads: int) -> torch.Tensor:
+    assert qkv.is_contiguous() and out.is_contiguous() and qkv.numel() == B * L * 3 * D
+    assert out.numel() == B * L * D and out.dtype == qkv.dtype
+    assert tok.dtype == torch.int32 and tok.is_contiguous() and tok.dim() == 2
+    assert grp is None or (grp.dtype == torch.uint8 and grp.shape == tok.shape and grp.is_contiguous())
+    assert qkv_bias is None or (qkv_bias.dtype == torch.float32 and qkv_bias.numel() == 3 * D)
+    n_windows, n_tok = tok.shape
+    _check(load().aurora_hip_window_attention(_ptr(qkv), _ptr(qkv_bias), _ptr(out), _ptr(tok), _ptr(grp),
+                                              B, L, D, heads, n_windows, n_tok, dtype_code(qkv.dtype),
+                                              _stream()))
+    return out
+
+
+def layernorm(y: torch.Tensor, gain: Optional[torch.Tensor], shift: Optional[torch.Tensor], *,
+              res: Optional[torch.Tensor] = None, res_mod: int = 0,
+              out_f32: Optional[torch.Tensor] = None, out_t: Optional[torch.Tensor] = None,
+              eps: float = 1e-5, d: Optional[int] = None) -> None:
+    ldy, dy = _rows(y)
+    D = d if d is not None else dy
+    M = y.shape[0]
+    for v in (gain, shift):
+        assert v is None or (v.dtype == torch.float32 and v.numel() >= D and v.is_contiguous())
+    ldr = ldo = ldt = 0
+    if res is not None:
+        assert res.dtype == torch.float32
+        ldr, _ = _rows(res)
+    if out_f32 is not None:
+        assert out_f32.dtype == torch.float32 and out_f32.shape[0] == M
+        ldo, _ = _rows(out_f32)
+    if out_t is not None:
+        assert out_t.dtype == y.dtype and out_t.shape[0] == M
+        ldt, _ = _rows(out_t)
+    _check(load().aurora_hip_layernorm(_ptr(y), ldy, _ptr(gain), _ptr(shift), _ptr(res), ldr, res_mod,
+                                       _ptr(out_f32), ldo, _ptr(out_t), ldt, M, D, eps,
+                                       dtype_code(y.dtype), _stream()))
+
+
+def merge_ln(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, out: torch.Tensor,
+             B: int, C: int, H: int, W: int, D: int, eps: float = 1e-5) -> torch.Tensor:
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == B * C * H * W * D
+    assert out.is_contiguous() and out.numel() == B * C * ((H + 1) // 2) * ((W + 1) // 2) * 4 * D
+    _check(load().aurora_hip_merge_ln(_ptr(x), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, C, H, W, D, eps,
+                                      dtype_code(out.dtype), _stream()))
+    return out
+
+
+def split_ln(y: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, out: torch.Tensor,
+             B: int, C: int, H: int, W: int, Dq: int, crop_h: int, crop_w: int,
+             eps: float = 1e-5) -> torch.Tensor:
+    assert y.is_contiguous() and y.numel() == B * C * H * W * 4 * Dq and y.dtype == out.dtype
+    assert out.is_contiguous() and out.numel() == B * C * (2 * H - crop_h) * (2 * W - crop_w) * Dq
+    _check(load().aurora_hip_split_ln(_ptr(y), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, C, H, W, Dq,
+                                      crop_h, crop_w, eps, dtype_code(y.dtype), _stream()))
+    return out
+
+
+def patchify(desc: list[PatchVar], out: torch.Tensor, k_offset: int, k_total: int, B: int, T: int,
+             n_lvl: int, Hp: int, Wp: int, P: int) -> None:
+    Kpad = out.shape[1]
+    assert out.is_contiguous() and out.shape[0] == n_lvl * B * Hp * Wp
+    arr = (PatchVar * len(desc))(*desc)
+    _check(load().aurora_hip_patchify(arr, len(desc), _ptr(out), Kpad, k_offset, k_total, B, T, n_lvl,
+                                      Hp, Wp, P, dtype_code(out.dtype), _stream()))
+
+
+def perceiver_attention(q: torch.Tensor, q_col_stride: int, kv: torch.Tensor, out: torch.Tensor,
+                        B: int, cols_per_b: int, kv_bstride: int, kv_lstride: int, Lq: int, Lk: int,
+                        heads: int, head_dim: int) -> torch.Tensor:
+    assert q.is_contiguous() and kv.is_contiguous() and out.is_contiguous()
+    assert q.dtype == kv.dtype == out.dtype
+    _check(load().aurora_hip_perceiver_attention(_ptr(q), q_col_stride, _ptr(kv), _ptr(out), B,
+                                                 cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads,
+                                                 head_dim, dtype_code(q.dtype), _stream()))
+    return out
+
+
+def assemble_tokens(surf: torch.Tensor, agg: torch.Tensor, pos_scale: torch.Tensor,
+                    time_emb: torch.Tensor, out_f32: torch.Tensor, out_t: Optional[torch.Tensor],
+                    B: int, Cl: int, L: int, D: int) -> None:
+    for t in (surf, agg, pos_scale, time_emb, out_f32):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    code = BF16 if out_t is not None else F32
+    _check(load().aurora_hip_assemble_tokens(_ptr(surf), _ptr(agg), _ptr(pos_scale), _ptr(time_emb),
+                                             _ptr(out_f32), _ptr(out_t), B, Cl, L, D, code, _stream()))
+
+
+def unpatchify(y: torch.Tensor, desc: list[UnpatchVar], B: int, n_lvl: int, Hp: int, Wp: int,
+               P: int) -> None:
+    ldy, _ = _rows(y)
+    assert y.dtype == torch.float32
+    arr = (UnpatchVar * len(desc))(*desc)
+    _check(load().aurora_hip_unpatchify(_ptr(y), ldy, arr, len(desc), B, n_lvl, Hp, Wp, P, _stream()))
+
+
+def copy2d(src: torch.Tensor, dst: torch.Tensor, cols: Optional[int] = None) -> None:
+    lds_, cs = _rows(src)
+    ldd, _ = _rows(dst)
+    assert src.dtype == dst.dtype and src.shape[0] == dst.shape[0]
+    _check(load().aurora_hip_copy2d(_ptr(src), lds_, _ptr(dst), ldd, src.shape[0],
+                                    cols if cols is not None else cs, dtype_code(src.dtype), _stream()))
+
+
+def convert(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    assert {src.dtype, dst.dtype} == {torch.float32, torch.bfloat16}
+    _check(load().aurora_hip_convert(_ptr(src), _ptr(dst), src.numel(), dtype_code(src.dtype), _stream()))
+    return dst

@@ -1,0 +1,193 @@
+/*
+ * aurora_hip.h -- C ABI of libaurora_hip.so, the MI355X (gfx950) compute library behind
+ * aurora_amd.Aurora.forward / rollout.
+ *
+ * The reference (microsoft/aurora) has no FFI: its operator boundary is the torch.nn.Module
+ * call interface.  Every entry point below therefore replaces one
+ * torch-level operator group of the reference's hot path and cites it.  All pointers are raw
+ * DEVICE pointers (hipMalloc'ed / torch-allocated), `stream` is a hipStream_t passed as void*,
+ * sizes are element counts unless stated, strides ("ld*") are in elements.  No torch types.
+ * Every function only enqueues work on `stream` and returns 0 on success or a negative
+ * AURORA_E_* code; aurora_hip_last_error() describes the last failure of the calling thread.
+ *
+ * dtype codes: AURORA_F32 = 0 (float), AURORA_BF16 = 1 (bfloat16, raw uint16 storage).
+ */
+#ifndef AURORA_HIP_H
+#define AURORA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AURORA_F32 0
+#define AURORA_BF16 1
+
+#define AURORA_OK 0
+#define AURORA_E_ARG (-1)     /* invalid argument (shape / alignment / dtype) */
+#define AURORA_E_LAUNCH (-2)  /* HIP launch error */
+
+#define AURORA_ACT_NONE 0
+#define AURORA_ACT_GELU 1 /* exact erf GELU (torch.nn.GELU default) */
+#define AURORA_ACT_SILU 2 /* x * sigmoid(x) (time_mlp / AdaLN modulation, swin3d.py:805-809, film.py:28) */
+
+const char* aurora_hip_last_error(void);
+int aurora_hip_version(void);
+
+/* ---- dense linear layers ------------------------------------------------------------------
+ * C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ residual[M,N]);  W is nn.Linear's (out,in)
+ * row-major weight.  A, W, C share `dtype`; accumulation is fp32 on the MFMA units
+ * (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x4_f32).  bias and residual are fp32 (nullable).
+ * C2 (nullable) receives a second copy of the result in the OTHER dtype (fp32 <-> bf16).
+ * ldr == 0 broadcasts one residual row to every output row.
+ * Constraints: K * sizeof(dtype) % 128 == 0 (zero-pad K otherwise); lda/ldw multiples of
+ * 16 bytes; operand pointers 16-byte aligned.  Outputs whose rows are not 16-byte aligned take
+ * a scalar store path.
+ * Replaces F.linear call sites: swin3d.py:59-66,153,169,554,609-612, perceiver.py:79-88,
+ * 141-152, encoder.py:318-363, decoder.py:214-263, film.py:48, patchembed.py:112 (as GEMM
+ * over unfolded patches).
+ */
+int aurora_hip_linear(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                      void* C, int64_t ldc, void* C2, int64_t ldc2,
+                      const float* residual, int64_t ldr,
+                      int64_t M, int N, int K, int dtype, int act, void* stream);
+
+/* ---- 3D shifted-window attention core ------------------------------------------------------
+ * For every window w and head h: O = softmax(Q K^T / sqrt(hd) + mask) V over the window's
+ * `win_tokens` (<= 144) tokens.  qkv: [B][L][3*D] with columns q | k | v, each head-major
+ * (swin3d.py:153-155).  The roll / pad / window-partition / reverse / crop / un-roll index
+ * permutations of swin3d.py:471-505 are folded into `tok` (int32 [n_windows][win_tokens],
+ * token index inside one batch element or -1 for a zero-padded position; padded positions
+ * carry q = k = v = qkv_bias, exactly as Linear(0) does in the reference).  `grp`
+ * (uint8 [n_windows][win_tokens], nullable) holds the communication-group labels of
+ * compute_3d_shifted_window_mask (swin3d.py:303-360): score += -100 where labels differ.
+ * Output O: [B][L][D], token order, padded positions are not written.  head_dim must be 64.
+ * Replaces WindowAttention.forward's SDPA (swin3d.py:154-168) + swin3d.py:177-285,471-505.
+ */
+int aurora_hip_window_attention(const void* qkv, const float* qkv_bias, void* out,
+                                const int32_t* tok, const uint8_t* grp,
+                                int B, int64_t L, int D, int heads, int n_windows, int win_tokens,
+                                int dtype, void* stream);
+
+/* ---- (adaptive) layer norm with residual --------------------------------------------------
+ * out[r,:] = res[r % res_mod? ,:] + LN(y[r,:]) * gain[:] + shift[:]   (res nullable)
+ * y: [M][D] of `dtype` with row stride ldy; statistics in fp32, eps as given.
+ * gain/shift: fp32 [D] (AdaLN: scale_bias + scale, shift -- film.py:48-49; affine LN: weight,
+ * bias).  res: fp32, row stride ldr; row index is r, or r % res_mod when res_mod > 0
+ * (Perceiver latents broadcast over grid columns, perceiver.py:224-232).
+ * out_f32 (nullable, stride ldo) and out_t (nullable, `dtype`, stride ldt) receive the result.
+ * Replaces swin3d.py:507-508, perceiver.py:224-232, encoder.py:320, perceiver.py:144-147.
+ */
+int aurora_hip_layernorm(const void* y, int64_t ldy, const float* gain, const float* shift,
+                         const float* res, int64_t ldr, int64_t res_mod,
+                         float* out_f32, int64_t ldo, void* out_t, int64_t ldt,
+                         int64_t M, int D, float eps, int dtype, void* stream);
+
+/* ---- patch merging: 2x2 gather + LayerNorm(4D) -------------------------------------------
+ * x: fp32 residual stream [B][C][H][W][D] -> out `dtype` [B][C][H2][W2][4D], H2 = ceil(H/2),
+ * features ordered (h, w, D), zero padding at the bottom/right (swin3d.py:526-553).
+ * The following Linear(4D, 2D) is an aurora_hip_linear call.
+ */
+int aurora_hip_merge_ln(const float* x, const float* ln_w, const float* ln_b, void* out,
+                        int B, int C, int H, int W, int D, float eps, int dtype, void* stream);
+
+/* ---- patch splitting: pixel shuffle + crop + LayerNorm(D/2) ------------------------------
+ * y: `dtype` [B][C][H][W][2D'] with 2D' = 4*Dq (output of lin1) -> out `dtype`
+ * [B][C][2H-crop_h][2W-crop_w][Dq]  (swin3d.py:574-611).
+ */
+int aurora_hip_split_ln(const void* y, const float* ln_w, const float* ln_b, void* out,
+                        int B, int C, int H, int W, int Dq, int crop_h, int crop_w, float eps,
+                        int dtype, void* stream);
+
+/* ---- patch embedding front end: normalise + unfold ----------------------------------------
+ * Builds the GEMM operand of LevelPatchEmbed (patchembed.py:100-115):
+ * out[((c*B + b)*Hp + hp)*Wp + wp][k_offset + (v*T + t)*P*P + i*P + j] =
+ *     f_v( (src_v[b,t,c,hp*P+i,wp*P+j] - loc_v[c]) * inv_scale_v[c] )
+ * rows are ordered (level, batch, patch) so that one level's rows are contiguous (per-level
+ * weights / biases are then plain row ranges).  The Batch.normalise affine map
+ * (batch.py:94-116) is fused in.  Columns [K_total, Kpad) are zero-filled by the call whose
+ * variables end at K_total.  `desc` is a HOST array of n_vars (<= 32) descriptors; their
+ * `src`, `loc`, `inv_scale` members are device pointers.  Strides are in elements and may be
+ * 0 (static variables broadcast over batch/history/level; constant planes).
+ * transform codes: 0 none, 1 clamp(min=0) (aurora.py:301-317), 2 clamp + air-pollution
+ * feature combiner (aurora.py:733-742) with Linear(2,1) weights tw0, tw1 and bias tb.
+ */
+typedef struct aurora_patch_var {
+  const float* src;       /* device: first element of the variable                           */
+  int64_t stride_b;       /* element strides: batch, history step, level, latitude, longitude */
+  int64_t stride_t;
+  int64_t stride_c;
+  int64_t stride_h;
+  int64_t stride_w;
+  const float* loc;       /* device [n_lvl] location                                          */
+  const float* inv_scale; /* device [n_lvl] 1/scale                                           */
+  int32_t transform;
+  float tw0, tw1, tb;
+} aurora_patch_var;
+
+int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, void* out, int64_t Kpad,
+                        int k_offset, int K_total, int B, int T, int n_lvl, int Hp, int Wp, int P,
+                        int dtype, void* stream);
+
+/* ---- small-set cross attention of the Perceiver resamplers ---------------------------------
+ * Per grid column col in [0, n_cols) and head: softmax(q k^T / sqrt(hd)) v over Lk keys.
+ * q: fp32/bf16 [Lq][inner] shared by all columns when q_col_stride == 0, else rows
+ * (col*Lq + i).  kv: key j of column (b, l) is one row, columns k | v
+ * (2*inner), row index b*kv_bstride + j*kv_lstride + l.  out rows (col*Lq + i), [inner].  Replaces perceiver.py:141-152 as used by
+ * encoder.py:184-196 (Lq=3, Lk=levels) and decoder.py:156-166 (Lq=levels, Lk=3).
+ */
+int aurora_hip_perceiver_attention(const void* q, int64_t q_col_stride, const void* kv, void* out,
+                                   int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
+                                   int Lq, int Lk, int heads, int head_dim, int dtype, void* stream);
+
+/* ---- token assembly at the encoder output -------------------------------------------------
+ * x[b][c][l][:] = (c == 0 ? surf[b][l][:] : agg[(b*L + l)*(Cl-1) + c-1][:])
+ *                 + pos_scale[l][:] + time_emb[b][:]
+ * (encoder.py:332-363).  Writes the fp32 stream and, if out_t != NULL, a `dtype` copy.
+ */
+int aurora_hip_assemble_tokens(const float* surf, const float* agg, const float* pos_scale,
+                               const float* time_emb, float* out_f32, void* out_t,
+                               int B, int Cl, int64_t L, int D, int dtype, void* stream);
+
+/* ---- decoder back end: unpatchify + post-decoder hooks + clamp + unnormalise ----------------
+ * y: fp32 [(b*L + l)*n_lvl + c][ldy] head outputs (decoder.py:214-263, util.py:18-41); variable
+ * v, level c, in-patch pixel (i, j) sits in column col0 + c*lvl_stride + i*P + j (lvl_stride != 0
+ * for level-conditioned heads).  Writes dst_v[b][c][hp*P+i][wp*P+j] = g(z) * scale_v[c] + loc_v[c]
+ * with Batch.unnormalise (batch.py:118-140) fused, where
+ *   z = y                                         plain variables
+ *   z = y + (1 + y_mod) * (prev - loc) * inv      difference prediction (aurora.py:761-779),
+ *                                                 y_mod at mod_col0 (>= 0), prev the raw previous
+ *                                                 state of the same variable
+ *   then z = min(z, 1) on the levels in clamp_max1_levels (bit c; SO2 fix aurora.py:781-794)
+ *   then g = clamp(min=0) if clamp_min0 (aurora.py:368-388).
+ * `desc`: HOST array of n_vars (<= 32) descriptors with device pointers inside.
+ */
+typedef struct aurora_unpatch_var {
+  float* dst;             /* [B][n_lvl][H][W] contiguous                                      */
+  const float* loc;       /* device [n_lvl]                                                   */
+  const float* scale;     /* device [n_lvl]                                                   */
+  int32_t clamp_min0;
+  int32_t col0;
+  int32_t lvl_stride;
+  int32_t mod_col0;       /* -1: no modulation head                                           */
+  const float* prev;      /* device, raw units: prev[b*prev_sb + c*prev_sc + h*prev_sh + w]   */
+  int64_t prev_sb, prev_sc, prev_sh;
+  const float* inv_scale; /* device [n_lvl] 1/scale (only read when mod_col0 >= 0)            */
+  uint32_t clamp_max1_levels;
+} aurora_unpatch_var;
+
+int aurora_hip_unpatchify(const float* y, int64_t ldy, const aurora_unpatch_var* desc, int n_vars,
+                          int B, int n_lvl, int Hp, int Wp, int P, void* stream);
+
+/* ---- utility ------------------------------------------------------------------------------ */
+/* dst[r, 0:cols] = src[r, 0:cols] for r < rows (row strides in elements of `dtype`). */
+int aurora_hip_copy2d(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows,
+                      int64_t cols, int dtype, void* stream);
+/* dst (other dtype) = convert(src): n elements, fp32 -> bf16 (round-nearest-even) or back. */
+int aurora_hip_convert(const void* src, void* dst, int64_t n, int src_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AURORA_HIP_H */

@@ -1,0 +1,55 @@
+"""The C-ABI library builds/loads here (no GPU) and exports every symbol include/aurora_hip.h declares."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def built():
+    from aurora_amd.build import build_library
+
+    return build_library(force=False, verbose=False)
+
+
+def test_header_symbols_are_exported(built):
+    header = (ROOT / "include" / "aurora_hip.h").read_text()
+    declared = set(re.findall(r"\b(aurora_hip_\w+)\s*\(", header))
+    assert len(declared) >= 12
+    lib = ctypes.CDLL(str(built))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    from aurora_amd.engine import lib as shim
+
+    assert set(shim.EXPORTED_SYMBOLS) == declared
+    assert shim.load().aurora_hip_version() >= 1
+
+
+def test_ctypes_structs_match_header_layout():
+    from aurora_amd.engine import lib as shim
+
+    # field-for-field with the typedefs in include/aurora_hip.h
+    assert [f[0] for f in shim.PatchVar._fields_] == [
+        "src", "stride_b", "stride_t", "stride_c", "stride_h", "stride_w", "loc", "inv_scale",
+        "transform", "tw0", "tw1", "tb"]
+    assert ctypes.sizeof(shim.PatchVar) == 80
+    assert [f[0] for f in shim.UnpatchVar._fields_] == [
+        "dst", "loc", "scale", "clamp_min0", "col0", "lvl_stride", "mod_col0", "prev", "prev_sb",
+        "prev_sc", "prev_sh", "inv_scale", "clamp_max1_levels"]
+    assert ctypes.sizeof(shim.UnpatchVar) == 88
+
+
+def test_argument_errors_surface_without_a_gpu(built):
+    """Argument validation happens before any launch, so it is testable on the CPU box."""
+    lib = ctypes.CDLL(str(built))
+    lib.aurora_hip_last_error.restype = ctypes.c_char_p
+    from aurora_amd.engine import lib as shim
+
+    fn = shim.load().aurora_hip_linear
+    code = fn(16, 40, 16, 40, None, 16, 8, None, 0, None, 0, 4, 8, 40, 0, 0, None)  # K=40 fp32: not 32-multiple
+    assert code == -1 and b"multiple" in shim.load().aurora_hip_last_error()
+    code = shim.load().aurora_hip_window_attention(16, None, 16, 16, None, 1, 10, 96, 2, 1, 4, 1, None)
+    assert code == -1 and b"head_dim" in shim.load().aurora_hip_last_error()

@@ -1,0 +1,321 @@
+"""Per-operator parity of libaurora_hip (through the ctypes C-ABI shim) against CPU references.
+
+fp32 kernels are held to fp32-roundoff tolerances against fp64 torch-CPU evaluations; bf16
+kernels are compared, on bf16-rounded inputs, against fp64 evaluations of the same rounded
+inputs (so only accumulation order and the output rounding differ).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import aurora_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def lib():
+    from aurora_amd.engine import lib as L
+
+    L.load()
+    return L
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------
+# linear
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 80, 160), (128, 128, 32), (1, 512, 64), (1000, 100, 96),
+                                   (257, 1536, 512), (64, 27, 1408)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_fp32(M, N, K, act):
+    L = lib()
+    a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = a @ w.T + b
+    ref = F.gelu(ref) if act == 1 else (F.silu(ref) if act == 2 else ref)
+    ref = ref + r
+    ld = (N + 3) // 4 * 4
+    out = torch.full((M, ld), float("nan"), device=DEV)
+    out2 = torch.zeros((M, ld), dtype=torch.bfloat16, device=DEV)
+    L.linear(a.float().to(DEV), w.float().to(DEV), b.float().to(DEV), out, out2=out2,
+             residual=r.float().to(DEV), act=act, n=N)
+    torch.cuda.synchronize()
+    assert relerr(out[:, :N], ref) < 2e-6
+    assert relerr(out2[:, :N].float(), ref) < 5e-3
+    if ld > N:
+        assert torch.isnan(out[:, N:]).all()  # padding columns untouched
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (130, 64, 64), (1000, 1536, 512), (129, 80, 2048)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear_bf16(M, N, K, act):
+    L = lib()
+    a = rnd(M, K, seed=1).bfloat16()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16()
+    b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = a.double() @ w.double().T + b
+    ref = F.gelu(ref) if act == 1 else ref
+    ref = ref + r
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    out2 = torch.zeros((M, N), device=DEV)
+    L.linear(a.to(DEV), w.to(DEV), b.float().to(DEV), out, out2=out2, residual=r.float().to(DEV), act=act)
+    torch.cuda.synchronize()
+    assert relerr(out2, ref) < 5e-6           # fp32 copy: exact products, fp32 accumulation
+    assert relerr(out.float(), ref) < 5e-3    # bf16 copy: one rounding
+
+
+def test_linear_broadcast_residual_row_and_strided_views():
+    L = lib()
+    M, N, K = 200, 96, 64
+    a_full, w, row = rnd(M, 2 * K, seed=5), rnd(N, K, seed=6), rnd(1, N, seed=7)
+    a_dev = a_full.float().to(DEV)
+    out_full = torch.zeros((M, 3 * N), device=DEV)
+    L.linear(a_dev[:, K:], w.float().to(DEV), None, out_full[:, N:2 * N],
+             residual=row.float().to(DEV).expand(M, N))
+    torch.cuda.synchronize()
+    ref = a_full[:, K:] @ w.T + row
+    assert relerr(out_full[:, N:2 * N], ref) < 2e-6
+    assert (out_full[:, :N] == 0).all() and (out_full[:, 2 * N:] == 0).all()
+
+
+def test_linear_rejects_bad_k():
+    L = lib()
+    a, w = torch.zeros((4, 40), device=DEV), torch.zeros((8, 40), device=DEV)
+    with pytest.raises(ValueError, match="multiple"):
+        L.linear(a, w, None, torch.zeros((4, 8), device=DEV))
+
+
+# ------------------------------------------------------------------------------------------
+# window attention
+# ------------------------------------------------------------------------------------------
+def attention_reference(qkv, bias, tok, grp, B, Ltok, D, heads):
+    """Gather through the (already reference-checked) tables, SDPA per window, scatter back."""
+    nW, N = tok.shape
+    hd = D // heads
+    out = torch.zeros((B, Ltok, D), dtype=torch.float64)
+    tok_t = torch.from_numpy(tok.astype(np.int64))
+    for b in range(B):
+        rows = torch.where(tok_t[..., None] >= 0, qkv[b][tok_t.clamp(min=0)], bias.expand(nW, N, 3 * D))
+        q, k, v = rows.reshape(nW, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        mask = None
+        if grp is not None:
+            g = torch.from_numpy(grp.astype(np.int64))
+            mask = torch.where(g[:, None, :] != g[:, :, None], -100.0, 0.0)[:, None].double()
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        o = o.transpose(1, 2).reshape(nW, N, D)
+        valid = tok_t >= 0
+        out[b][tok_t[valid]] = o[valid]
+    return out
+
+
+ATTN_CASES = [((4, 12, 24), (2, 6, 12), 2), ((4, 13, 26), (2, 6, 12), 1), ((4, 7, 13), (2, 6, 12), 2),
+              ((4, 4, 8), (2, 6, 12), 4), ((4, 1, 2), (2, 6, 12), 1), ((2, 5, 9), (2, 3, 4), 1)]
+
+
+@pytest.mark.parametrize("res,window,heads", ATTN_CASES)
+@pytest.mark.parametrize("shifted", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_window_attention(res, window, heads, shifted, dtype):
+    from aurora_amd.engine import geometry
+
+    L = lib()
+    B, D = 2, 64 * heads
+    Ltok = res[0] * res[1] * res[2]
+    tok, grp, _ = geometry.window_tables(res, window, shifted)
+    qkv = rnd(B, Ltok, 3 * D, seed=11, scale=2.0).to(dtype)
+    bias = rnd(3 * D, seed=12)
+    bias_used = bias.to(dtype).double() if dtype == torch.bfloat16 else bias.float().double()
+    ref = attention_reference(qkv.double(), bias_used, tok, grp, B, Ltok, D, heads)
+    out = torch.full((B, Ltok, D), 7.0, dtype=dtype, device=DEV)
+    L.window_attention(qkv.to(DEV).contiguous(), bias.float().to(DEV), out,
+                       torch.from_numpy(tok).to(DEV), None if grp is None else torch.from_numpy(grp).to(DEV),
+                       B, Ltok, D, heads)
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert relerr(out.float(), ref) < tol
+
+
+# ------------------------------------------------------------------------------------------
+# layer norms
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [64, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_residual(D, dtype):
+    L = lib()
+    M = 37
+    y = (rnd(M, D, seed=1, scale=3.0) + 0.5).to(dtype)
+    gain, shift, res = rnd(D, seed=2) + 1, rnd(D, seed=3), rnd(5, D, seed=4)
+    ref = F.layer_norm(y.double(), (D,), eps=1e-5) * gain + shift + res[torch.arange(M) % 5]
+    out_f = torch.zeros((M, D), device=DEV)
+    out_t = torch.zeros((M, D), dtype=dtype, device=DEV)
+    L.layernorm(y.to(DEV), gain.float().to(DEV), shift.float().to(DEV), res=res.float().to(DEV), res_mod=5,
+                out_f32=out_f, out_t=out_t)
+    torch.cuda.synchronize()
+    assert relerr(out_f, ref) < 3e-6
+    assert relerr(out_t.float(), ref) < (3e-6 if dtype == torch.float32 else 5e-3)
+
+
+def test_layernorm_in_place_on_column_block():
+    L = lib()
+    M, inner = 50, 128
+    kv = rnd(M, 2 * inner, seed=9).float().to(DEV)
+    orig = kv.clone()
+    w, b = rnd(inner, seed=1) + 1, rnd(inner, seed=2)
+    L.layernorm(kv, w.float().to(DEV), b.float().to(DEV), out_f32=kv, d=inner)
+    torch.cuda.synchronize()
+    ref = F.layer_norm(orig[:, :inner].double().cpu(), (inner,), w, b)
+    assert relerr(kv[:, :inner], ref) < 3e-6
+    assert torch.equal(kv[:, inner:], orig[:, inner:])
+
+
+@pytest.mark.parametrize("H,W", [(12, 24), (13, 26), (7, 13)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_merge_and_split(H, W, dtype):
+    L = lib()
+    B, C, D = 2, 4, 64
+    x = rnd(B, C * H * W, D, seed=1)
+    sd = {"m.norm.weight": rnd(4 * D, seed=2) + 1, "m.norm.bias": rnd(4 * D, seed=3),
+          "m.reduction.weight": torch.eye(4 * D, dtype=torch.float64)}
+    ref = oracle.patch_merge(sd, "m", x, (C, H, W))  # identity reduction: the LN output itself
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    out = torch.zeros((B * C * H2 * W2, 4 * D), dtype=dtype, device=DEV)
+    L.merge_ln(x.float().to(DEV).contiguous(), sd["m.norm.weight"].float().to(DEV),
+               sd["m.norm.bias"].float().to(DEV), out, B, C, H, W, D)
+    torch.cuda.synchronize()
+    tol = 3e-6 if dtype == torch.float32 else 5e-3
+    assert relerr(out.float(), ref.reshape(-1, 4 * D)) < tol
+
+    # split: (C, H2, W2) with 2D' features back to (C, H, W), crop = odd remainders
+    Dq = 32
+    y = rnd(B, C * H2 * W2, 4 * Dq, seed=5).to(dtype)
+    sd2 = {"s.lin1.weight": torch.eye(4 * Dq, dtype=torch.float64), "s.norm.weight": rnd(Dq, seed=6) + 1,
+           "s.norm.bias": rnd(Dq, seed=7), "s.lin2.weight": torch.eye(Dq, dtype=torch.float64)}
+    ref2 = oracle.patch_split(sd2, "s", y.double(), (C, H2, W2), (0, H % 2, W % 2))
+    out2 = torch.zeros((B * C * H * W, Dq), dtype=dtype, device=DEV)
+    L.split_ln(y.to(DEV).contiguous(), sd2["s.norm.weight"].float().to(DEV), sd2["s.norm.bias"].float().to(DEV),
+               out2, B, C, H2, W2, Dq, H % 2, W % 2)
+    torch.cuda.synchronize()
+    assert relerr(out2.float(), ref2.reshape(-1, Dq)) < tol
+
+
+# ------------------------------------------------------------------------------------------
+# embed / unembed
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P", [3, 4, 10])
+def test_patchify_matches_conv_unfold(P):
+    L = lib()
+    B, T, C, Hp, Wp, V = 2, 2, 3, 5, 7, 3
+    H, W = Hp * P, Wp * P
+    x = rnd(B, T, V, C, H + 1, W, seed=1, scale=5.0).float()  # one extra latitude row (cropped view)
+    static = rnd(H, W, seed=2).float()
+    loc, sc = rnd(V + 1, C, seed=3).float(), (rnd(V + 1, C, seed=4).abs() + 0.5).float()
+    xd, sdv = x.to(DEV), static.to(DEV)
+    descs, keep = [], []
+    for v in range(V + 1):
+        lo, inv = loc[v].to(DEV).contiguous(), (1.0 / sc[v].double()).float().to(DEV).contiguous()
+        keep += [lo, inv]
+        if v < V:
+            t = xd[:, :, v, :, :H, :]
+            sb, st, scs, sh, sw = t.stride()
+            descs.append(L.PatchVar(t.data_ptr(), sb, st, scs, sh, sw, lo.data_ptr(), inv.data_ptr(),
+                                    1 if v == 1 else 0, 0.0, 0.0, 0.0))
+        else:
+            descs.append(L.PatchVar(sdv.data_ptr(), 0, 0, 0, W, 1, lo.data_ptr(), inv.data_ptr(), 0, 0.0, 0.0, 0.0))
+    K = (V + 1) * T * P * P
+    Kpad = (K + 31) // 32 * 32
+    out = torch.full((C * B * Hp * Wp, Kpad), float("nan"), device=DEV)
+    L.patchify(descs, out, 0, K, B, T, C, Hp, Wp, P)
+    torch.cuda.synchronize()
+    # reference: normalise, clamp var 1, unfold
+    xn = (x[..., :H, :] - loc[:V, :, None, None]) / sc[:V, :, None, None]
+    xn[:, :, 1] = xn[:, :, 1].clamp(min=0)
+    sn = ((static[None] - loc[V, :, None, None]) / sc[V, :, None, None])  # (C, H, W)
+    full = torch.cat([xn, sn[None, None, None].expand(B, T, 1, C, H, W)], dim=2)  # (B,T,V+1,C,H,W)
+    pat = full.reshape(B, T, V + 1, C, Hp, P, Wp, P).permute(3, 0, 4, 6, 2, 1, 5, 7)  # c b hp wp v t i j
+    ref = pat.reshape(C * B * Hp * Wp, K)
+    assert relerr(out[:, :K], ref) < 2e-6
+    assert (out[:, K:] == 0).all()
+
+
+def test_unpatchify_matches_oracle():
+    L = lib()
+    B, CA, Hp, Wp, P, V = 2, 3, 4, 6, 4, 3
+    H, W = Hp * P, Wp * P
+    y = rnd(B * Hp * Wp * CA, V * P * P, seed=1).float()
+    loc, sc = rnd(V, CA, seed=2).float(), (rnd(V, CA, seed=3).abs() + 0.5).float()
+    # oracle layout: (B, L, C, V*P*P) with V fastest
+    y_or = y.reshape(B, Hp * Wp, CA, V, P * P).permute(0, 1, 2, 4, 3).reshape(B, Hp * Wp, CA, P * P * V)
+    ref = oracle.unpatchify(y_or.double(), V, H, W, P)  # (B, V, C, H, W)
+    ref[:, 1] = ref[:, 1].clamp(min=0)
+    ref = ref * sc.double()[None, :, :, None, None] + loc.double()[None, :, :, None, None]
+    out = torch.zeros((V, B, CA, H, W), device=DEV)
+    keep, descs = [], []
+    for v in range(V):
+        lo, s_ = loc[v].to(DEV).contiguous(), sc[v].to(DEV).contiguous()
+        keep += [lo, s_]
+        d = L.UnpatchVar(out[v].data_ptr(), lo.data_ptr(), s_.data_ptr(), 1 if v == 1 else 0, v * P * P)
+        d.mod_col0 = -1
+        descs.append(d)
+    L.unpatchify(y.to(DEV), descs, B, CA, Hp, Wp, P)
+    torch.cuda.synchronize()
+    assert relerr(out.permute(1, 0, 2, 3, 4), ref) < 2e-6
+
+
+@pytest.mark.parametrize("Lq,Lk,hd", [(3, 13, 32), (13, 3, 64), (3, 4, 16)])
+def test_perceiver_attention(Lq, Lk, hd):
+    L = lib()
+    B, cols, heads = 2, 50, 4
+    inner = heads * hd
+    q = rnd(Lq, inner, seed=1)
+    kv = rnd(B * Lk * cols, 2 * inner, seed=2)  # rows (b, j, l)
+    out = torch.zeros((B * cols * Lq, inner), device=DEV)
+    L.perceiver_attention(q.float().to(DEV), 0, kv.float().to(DEV), out, B, cols, Lk * cols, cols, Lq, Lk, heads, hd)
+    torch.cuda.synchronize()
+    kvr = kv.reshape(B, Lk, cols, 2, heads, hd).permute(3, 0, 2, 4, 1, 5)  # (2, B, cols, heads, Lk, hd)
+    qq = q.reshape(Lq, heads, hd).permute(1, 0, 2)[None, None].expand(B, cols, -1, -1, -1)
+    ref = F.scaled_dot_product_attention(qq, kvr[0], kvr[1])  # (B, cols, heads, Lq, hd)
+    ref = ref.permute(0, 1, 3, 2, 4).reshape(B * cols * Lq, inner)
+    assert relerr(out, ref) < 3e-6
+
+
+def test_assemble_tokens():
+    L = lib()
+    B, Cl, Lp, D = 2, 4, 30, 64
+    surf, agg = rnd(B * Lp, D, seed=1), rnd(B * Lp * (Cl - 1), D, seed=2)
+    ps, te = rnd(Lp, D, seed=3), rnd(B, D, seed=4)
+    out_f = torch.zeros((B * Cl * Lp, D), device=DEV)
+    out_b = torch.zeros((B * Cl * Lp, D), dtype=torch.bfloat16, device=DEV)
+    L.assemble_tokens(surf.float().to(DEV), agg.float().to(DEV), ps.float().to(DEV), te.float().to(DEV),
+                      out_f, out_b, B, Cl, Lp, D)
+    torch.cuda.synchronize()
+    x = torch.cat([surf.reshape(B, 1, Lp, D), agg.reshape(B, Lp, Cl - 1, D).permute(0, 2, 1, 3)], dim=1)
+    ref = (x + ps[None, None] + te[:, None, None]).reshape(-1, D)
+    assert relerr(out_f, ref) < 1e-6
+    assert relerr(out_b.float(), ref) < 5e-3
+
+
+def test_convert_and_copy2d():
+    L = lib()
+    x = rnd(1000, 37, seed=1).float().to(DEV).contiguous()
+    y = L.convert(x, torch.empty_like(x, dtype=torch.bfloat16))
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), x.cpu().bfloat16())  # round-to-nearest-even, bit exact
+    z = L.convert(y, torch.empty_like(x))
+    torch.cuda.synchronize()
+    assert torch.equal(z.cpu(), y.cpu().float())
+    src = rnd(20, 64, seed=2).float().to(DEV)
+    dst = torch.zeros((20, 128), device=DEV)
+    L.copy2d(src, dst[:, 64:])
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, 64:], src) and (dst[:, :64] == 0).all()
