@@ -84,13 +84,17 @@ class Engine:
         self._embed_w_cache: dict = {}
         self._stat_cache: dict = {}
         self._lora_sets: "OrderedDict[object, dict]" = OrderedDict()
+        self.debug_hook = None  # optional callable(tag, tensor) at stage boundaries (tools/debug_blocks.py)
         self._pack_static()
 
     # ---------------------------------------------------------------------------------------
     # helpers
     # ---------------------------------------------------------------------------------------
     def _stamp(self) -> int:
-        return sum(p._version for p in self.model.parameters())
+        try:
+            return sum(p._version for p in self.model.parameters())
+        except RuntimeError:  # inference tensors carry no version counter
+            return -1
 
     def is_stale(self) -> bool:
         return self._stamp() != self._param_stamp
@@ -266,7 +270,7 @@ class Engine:
         Looked up by tensor identity first (a roll-out passes the same lat/lon objects from step
         to step, so no device->host copy happens per step), then by content.
         """
-        ident = (id(lat), id(lon), lat._version, lon._version)
+        ident = (id(lat), id(lon), lat.data_ptr(), lon.data_ptr())
         hit = self._grid_cache.get("ident")
         if hit is not None and hit[0] == ident:
             return hit[3]
@@ -602,6 +606,8 @@ class Engine:
         for i in range(n_enc):
             x_f, x_b = run_blocks(by_layer("enc", i), x_f, x_b, all_res[i])
             skips.append(x_f)
+            if self.debug_hook:
+                self.debug_hook(f"enc{i}", x_f)
             if i < n_enc - 1:
                 C, H, W = all_res[i]
                 m = self.merges[i]
@@ -617,6 +623,8 @@ class Engine:
                     lib.linear(mg, m["w"], None, nf)
                 del mg
                 x_f, x_b = nf, nb
+                if self.debug_hook:
+                    self.debug_hook(f"merge{i}", x_f)
 
         D0 = dims[0]
         L0 = int(np.prod(all_res[0]))
@@ -629,6 +637,8 @@ class Engine:
             x_f, x_b = run_blocks(blocks, x_f, x_b, all_res[idx], final_out=final_out)
             if last_layer and not blocks:
                 lib.copy2d(x_f, x_cat[:, :D0])
+            if self.debug_hook:
+                self.debug_hook(f"dec{i}", x_cat[:, :D0] if last_layer else x_f)
             if i < n_dec - 1:
                 C, H, W = all_res[idx]
                 s = self.splits[i]
@@ -656,6 +666,8 @@ class Engine:
                     lib.linear(sp, s["w2"], None, nf, residual=res)
                 del sp
                 x_f, x_b = nf, nb
+                if self.debug_hook:
+                    self.debug_hook(f"split{i}", x_f)
         lib.copy2d(skips[0], x_cat[:, D0:])
         return x_cat
 

@@ -125,6 +125,8 @@ def _stream() -> int:
 def _rows(t: torch.Tensor) -> tuple[int, int]:
     """(leading dimension in elements, inner size) of a 2-D view with unit inner stride."""
     assert t.dim() == 2 and t.stride(1) == 1, f"need a row-major 2-D view, got {t.shape} / {t.stride()}"
+    if t.shape[0] == 1:  # the stride of a size-1 dimension is arbitrary (often 0): irrelevant here
+        return max(t.stride(0), t.shape[1]), t.shape[1]
     return t.stride(0), t.shape[1]
 
 

@@ -29,8 +29,11 @@ def test_oracle_matches_reference_golden(name):
                 for k, v in d.items():
                     ref = torch.from_numpy(gold[f"s{s}.{kind}.{k}"])
                     assert v.shape == ref.shape
-                    # golden is a float32 cast of the fp64 reference output
-                    assert helpers.rel_err(v, ref) < 2e-7, (name, s, kind, k)
+                    # The golden is a float32 cast of the fp64 reference output (6e-8).  The bound also
+                    # has to absorb the host CPU: lat/lon pooling and patch areas are fp32 upstream
+                    # even in an fp64 model, and their last-bit differences between CPU families
+                    # reach the output at the 1e-6 level (measured 2e-7 .. 3e-6 on EPYC vs Xeon).
+                    assert helpers.rel_err(v, ref) < 2e-5, (name, s, kind, k)
                     seen += 1
     assert seen == len(gold)
 
