@@ -30,6 +30,7 @@ torch is used here for device memory (torch.empty / views), layout plumbing at p
 from __future__ import annotations
 
 import dataclasses
+import os
 from collections import OrderedDict
 from datetime import timedelta
 from typing import Optional, Sequence
@@ -378,9 +379,26 @@ class Engine:
         assert md.lon.dtype in (torch.float32, torch.float64), f"Longitude num. unstable: {md.lon.dtype}."
         assert cfg.latent_levels % cfg.window_size[0] == 0, "latent levels must be divisible by ws[0]"
 
+        trace = os.environ.get("AURORA_TRACE")
+        if trace:
+            import sys
+            import time
+
+            def mark(tag, t0=[time.perf_counter()]):  # noqa: B006
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                print(f"[aurora_amd] {tag}: {(now - t0[0]) * 1e3:.1f} ms", file=sys.stderr, flush=True)
+                t0[0] = now
+        else:
+            mark = lambda tag: None  # noqa: E731
+        mark("step start")
         x_f, x_b = self._encode(batch, B, T, H, W, Hp, Wp, levels)
+        mark("encoder")
         x_cat = self._backbone(x_f, x_b, B, patch_res, md.rollout_step)
-        return self._decode(x_cat, batch, B, H, W, Hp, Wp, levels)
+        mark("backbone")
+        out = self._decode(x_cat, batch, B, H, W, Hp, Wp, levels)
+        mark("decoder")
+        return out
 
     # -- encoder ------------------------------------------------------------------------------
     def _var_desc(self, t: torch.Tensor, kind: str, name: str, levels: tuple, transform=0, comb=None) -> lib.PatchVar:

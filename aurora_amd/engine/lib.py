@@ -130,6 +130,50 @@ def _rows(t: torch.Tensor) -> tuple[int, int]:
     return t.stride(0), t.shape[1]
 
 
+# ---- optional per-launch timing (bench.py / tools): HIP events on the launch stream -----------
+_profile: Optional[list] = None
+
+
+def profile_start() -> None:
+    """Start recording (kernel, algorithmic work, start event, stop event) for every launch."""
+    global _profile
+    _profile = []
+
+
+def profile_stop() -> dict:
+    """Stop recording; returns {kernel: {"launches", "ms", "work"}} (synchronises the device)."""
+    global _profile
+    rec, _profile = _profile or [], None
+    torch.cuda.synchronize()
+    out: dict = {}
+    for name, work, e0, e1 in rec:
+        d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+        d["launches"] += 1
+        d["ms"] += e0.elapsed_time(e1)
+        d["work"] += work
+    return out
+
+
+class _Timed:
+    """Brackets one launch with HIP events when profiling is on (torch.cuda.Event records on the
+    current stream, which is the stream every kernel of this library is launched on)."""
+
+    def __init__(self, name: str, work: float):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _profile is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _profile is not None:
+            self.e1.record()
+            _profile.append((self.name, self.work, self.e0, self.e1))
+        return False
+
+
 # ---- wrappers ------------------------------------------------------------------------------
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
            out2: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -151,9 +195,11 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.shape[0] == M
         ldr, _ = _rows(residual)
-    _check(load().aurora_hip_linear(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), _ptr(out), ldc, _ptr(out2),
-                                    ldc2, _ptr(residual), ldr, M, N, K, dtype_code(a.dtype), act,
-                                    _stream()))
+    name = "linear_bf16" if a.dtype == torch.bfloat16 else "linear_f32"
+    with _Timed(name, 2.0 * M * N * K):  # algorithmic FLOPs
+        _check(load().aurora_hip_linear(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), _ptr(out), ldc, _ptr(out2),
+                                        ldc2, _ptr(residual), ldr, M, N, K, dtype_code(a.dtype), act,
+                                        _stream()))
     return out
 
 
@@ -166,9 +212,12 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], out: t
     assert grp is None or (grp.dtype == torch.uint8 and grp.shape == tok.shape and grp.is_contiguous())
     assert qkv_bias is None or (qkv_bias.dtype == torch.float32 and qkv_bias.numel() == 3 * D)
     n_windows, n_tok = tok.shape
-    _check(load().aurora_hip_window_attention(_ptr(qkv), _ptr(qkv_bias), _ptr(out), _ptr(tok), _ptr(grp),
-                                              B, L, D, heads, n_windows, n_tok, dtype_code(qkv.dtype),
-                                              _stream()))
+    name = "window_attention_bf16" if qkv.dtype == torch.bfloat16 else "window_attention_f32"
+    # algorithmic bytes: q, k, v read + o written once over the padded windows
+    with _Timed(name, 4.0 * B * n_windows * n_tok * D * qkv.element_size()):
+        _check(load().aurora_hip_window_attention(_ptr(qkv), _ptr(qkv_bias), _ptr(out), _ptr(tok), _ptr(grp),
+                                                  B, L, D, heads, n_windows, n_tok, dtype_code(qkv.dtype),
+                                                  _stream()))
     return out
 
 
@@ -191,9 +240,12 @@ def layernorm(y: torch.Tensor, gain: Optional[torch.Tensor], shift: Optional[tor
     if out_t is not None:
         assert out_t.dtype == y.dtype and out_t.shape[0] == M
         ldt, _ = _rows(out_t)
-    _check(load().aurora_hip_layernorm(_ptr(y), ldy, _ptr(gain), _ptr(shift), _ptr(res), ldr, res_mod,
-                                       _ptr(out_f32), ldo, _ptr(out_t), ldt, M, D, eps,
-                                       dtype_code(y.dtype), _stream()))
+    nbytes = M * D * (y.element_size() + (4 if res is not None else 0) + (4 if out_f32 is not None else 0)
+                      + (y.element_size() if out_t is not None else 0))
+    with _Timed("layernorm", float(nbytes)):
+        _check(load().aurora_hip_layernorm(_ptr(y), ldy, _ptr(gain), _ptr(shift), _ptr(res), ldr, res_mod,
+                                           _ptr(out_f32), ldo, _ptr(out_t), ldt, M, D, eps,
+                                           dtype_code(y.dtype), _stream()))
 
 
 def merge_ln(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, out: torch.Tensor,

@@ -1,0 +1,209 @@
+"""Headline benchmark: forecast-steps/sec of one Aurora forward step (+6 h) on the 0.25-degree
+ERA5 grid (721 x 1440, 13 pressure levels, 2 history states), bf16 backbone (autocast=True).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one `Aurora.forward` of the 1.3 B-parameter AuroraPretrained configuration
+(BASELINE.json configs[1]) on a synthetic Batch that is already resident in HBM: patch embed +
+Perceiver encoder, 48 Swin blocks, Perceiver decoder, unpatchify -- nothing skipped.  Weights are
+random (`torch.manual_seed(0)`, zero-initialised AdaLN / LoRA tensors re-randomised), inputs are
+`randn` in normalised space mapped to physical units (`torch.manual_seed(1)`).
+
+With N > 1 every rank (one process per GPU) advances its own forecast (independent initial
+conditions = ensemble members); there is no collective on the data path, `value` is the number of
+forecast steps all ranks completed divided by the slowest rank's time ("weak" scaling).
+
+One JSON line on stdout (rank 0), with two extra objects:
+  roofline      the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / mean launch time measured
+                with HIP events on the launch stream during the timed steps, vs the 2.5 PF dense peak;
+                `attention` holds the same for the HBM-bound window-attention kernel (bytes / time
+                vs 8 TB/s).
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm) timed on this box's host
+                cores on a bounded sub-grid sample, scaled to the full grid by token count.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from datetime import datetime, timezone
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+LEVELS = (50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000)
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (6.29 TB/s measured achievable)
+FLOP_PER_STEP = 96.8e12
+
+
+def synthetic_batch(cfg, H, W, seed, device, levels=LEVELS):
+    from aurora_amd import Batch, Metadata, normalisation as nz
+
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    surf = {k: r(1, 2, H, W) * nz.scales[k] + nz.locations[k] for k in cfg.surf_vars}
+    static = {k: r(H, W) * nz.scales[k] + nz.locations[k] for k in cfg.static_vars}
+    atmos = {}
+    for k in cfg.atmos_vars:
+        loc = torch.tensor([nz.locations[f"{k}_{lv}"] for lv in levels])[:, None, None]
+        sc = torch.tensor([nz.scales[f"{k}_{lv}"] for lv in levels])[:, None, None]
+        atmos[k] = r(1, 2, len(levels), H, W) * sc + loc
+    md = Metadata(lat=torch.linspace(90, -90, H), lon=torch.linspace(0, 360, W + 1)[:-1],
+                  time=(datetime(2020, 6, 1, 12, 0, tzinfo=timezone.utc),), atmos_levels=levels)
+    return Batch(surf, static, atmos, md).to(device)
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg: str) -> None:
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def build_model(device):
+    import aurora_amd
+
+    torch.manual_seed(0)
+    # Build on the GPU: initialising 1.3 B parameters with CPU RNG kernels takes minutes.
+    with torch.device(device):
+        model = aurora_amd.AuroraPretrained(autocast=True)
+        with torch.no_grad():
+            for p in model.parameters():
+                if not p.any():  # zero-initialised AdaLN modulation: keep the blocks from being no-ops
+                    p.normal_(std=0.02)
+    return model.eval()
+
+
+def cpu_baseline(model, budget_s: float = 30.0) -> dict:
+    """Time the CPU oracle (port of the reference algorithm, fp32) on a bounded sub-grid sample."""
+    from aurora_amd import normalisation as nz
+    from oracle import aurora_oracle as oracle
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cfg = model.config
+    result = None
+    for (H, W, frac) in ((180, 360, 16), (360, 720, 4)):
+        b = synthetic_batch(cfg, H, W, 1, "cpu")
+        t0 = time.perf_counter()
+        with torch.inference_mode():
+            oracle.forward(sd, cfg, b.surf_vars, b.static_vars, b.atmos_vars, b.metadata.lat, b.metadata.lon,
+                           b.metadata.time, LEVELS, 0, nz.locations, nz.scales)
+        dt = time.perf_counter() - t0
+        result = {"value": 1.0 / (dt * frac), "unit": "forecast-steps/s", "cores": cores, "kind": "port",
+                  "sample": f"oracle fp32 forward on a {H}x{W} sub-grid (1/{frac} of the 720x1440 tokens) in "
+                            f"{dt:.1f} s, throughput scaled by 1/{frac}"}
+        if dt * 4.5 > budget_s:  # the next sample is 4x the tokens
+            break
+    return result
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from aurora_amd.engine import lib
+
+    log("building model")
+    model = build_model(device)
+    log("model on device; building batch")
+    batch = synthetic_batch(model.config, 721, 1440, 1 + rank, device)
+    log("batch on device")
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.inference_mode():
+        for i in range(args.warmup):
+            pred = model.forward(batch)
+            torch.cuda.synchronize()
+            log(f"warmup step {i} done")
+        barrier()
+        lib.profile_start()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pred = model.forward(batch)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    prof = lib.profile_stop()
+    log(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
+    assert torch.isfinite(pred.surf_vars["2t"]).all()
+
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        g = prof.get("linear_bf16", {"launches": 0, "ms": 0.0, "work": 0.0})
+        a = prof.get("window_attention_bf16", {"launches": 0, "ms": 0.0, "work": 0.0})
+        gemm_tf = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else 0.0
+        attn_gbs = a["work"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] else 0.0
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_summary.json"
+        if pmc.exists():
+            traffic = json.loads(pmc.read_text()).get("linear_bf16_hbm_bytes_per_launch")
+        out = {
+            "metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13",
+            "value": value, "unit": "forecast-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "AuroraPretrained(autocast=True) 1.3B, 0.25deg ERA5 721x1440, 13 levels, "
+                                   "T=2, batch 1 per GPU, one forward step (BASELINE.json configs[1])",
+                       "parallelism": f"replica x{world} (independent forecasts, no data-path collective)"},
+            "roofline": {
+                "kernel": "linear_kernel<bf16> (MFMA GEMM, all backbone linears)", "bound": "mfma",
+                "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": traffic,
+                "launches_per_step": g["launches"] / max(args.steps, 1),
+                "ms_per_step": g["ms"] / max(args.steps, 1),
+                "attention": {"kernel": "window_attention_bf16", "bound": "hbm", "achieved": attn_gbs,
+                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": attn_gbs / PEAK_HBM_GBS,
+                              "launches_per_step": a["launches"] / max(args.steps, 1),
+                              "ms_per_step": a["ms"] / max(args.steps, 1)},
+            },
+            "step_tflops": FLOP_PER_STEP / (ms_per_step * 1e-3) / 1e12,
+            "kernel_ms_per_step": {k: v["ms"] / max(args.steps, 1) for k, v in sorted(prof.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle sample")
+            out["cpu_baseline"] = cpu_baseline(model)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
