@@ -24,6 +24,8 @@
 // Workgroup ids are remapped so that each XCD (8 of them, private L2s, block b runs on XCD b % 8)
 // owns a contiguous range of tiles with the n-tiles of one m-tile adjacent: the activation tile
 // is then fetched from HBM once per XCD and re-used out of that XCD's L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace aurora {
@@ -104,6 +106,9 @@ __device__ __forceinline__ void store16<bf16_t>(bf16_t* dst, const float (&v)[16
   }
 }
 
+__device__ __forceinline__ void tile_of_block(uint32_t bid, uint32_t nb, uint32_t tiles_m, uint32_t tiles_n,
+                                              uint32_t& tile_m, uint32_t& tile_n);
+
 template <typename T> struct Other;
 template <> struct Other<float> { typedef bf16_t type; };
 template <> struct Other<bf16_t> { typedef float type; };
@@ -120,15 +125,11 @@ __global__ __launch_bounds__(THREADS, 2) void linear_kernel(const LinearArgs p) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- XCD-aware tile assignment (bijective for any block count) ----
-  const uint32_t bid = blockIdx.x, nb = (uint32_t)p.n_blocks;
-  const uint32_t q8 = nb >> 3, r8 = nb & 7;
-  const uint32_t xcd = bid & 7, idx = bid >> 3;
-  const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const uint32_t tile_m = logical / (uint32_t)p.tiles_n;
-  const int tile_n = (int)(logical - tile_m * (uint32_t)p.tiles_n);
+  // ---- XCD-aware, L2-friendly tile assignment (tile_of_block, below) ----
+  uint32_t tile_m, tile_n_u;
+  tile_of_block(blockIdx.x, (uint32_t)p.n_blocks, (uint32_t)(p.n_blocks / p.tiles_n), (uint32_t)p.tiles_n, tile_m, tile_n_u);
   const int64_t m0 = (int64_t)tile_m * BM;
-  const int n0 = tile_n * BN;
+  const int n0 = (int)tile_n_u * BN;
 
   // ---- per-thread staging addresses: 4 pieces of X and 4 of W per K-tile ----
   const char* src_x[4];
@@ -231,7 +232,221 @@ __global__ __launch_bounds__(THREADS, 2) void linear_kernel(const LinearArgs p) 
     }
     if (p.act == AURORA_ACT_GELU) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) v[t] = gelu_erf(v[t]);
+      for (int t = 0; t < 16; ++t) v[t] = gelu_for<T>(v[t]);
+    } else if (p.act == AURORA_ACT_SILU) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
+    }
+    if (p.res) {
+      const float* rp = p.res + m * p.ldr + nbase;
+      if (vec && n_left >= 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 rv = reinterpret_cast<const f32x4*>(rp)[q];
+          v[4 * q] += rv.x; v[4 * q + 1] += rv.y; v[4 * q + 2] += rv.z; v[4 * q + 3] += rv.w;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (t < n_left) v[t] += rp[t];
+      }
+    }
+    store16<T>(reinterpret_cast<T*>(p.C) + m * p.ldc + nbase, v, vec, n_left);
+    if (p.C2) store16<T2>(reinterpret_cast<T2*>(p.C2) + m * p.ldc2 + nbase, v, vec, n_left);
+  }
+}
+
+
+// =================================================================================================
+// Big-tile kernel for the backbone shapes (M >= 1024, N % 256 == 0): 256 x 256 tile, 512 threads =
+// 8 waves as 2 (m) x 4 (n), wave tile 128 x 64 = 8 x 4 fragments.
+//
+// Why: the 128 x 128 kernel above keeps one 32 KiB K-tile in flight per workgroup; with ~1-2 us of
+// HBM/L2 latency and ~0.2 us of MFMA work per tile the short-K GEMMs of stage 0 (K = 512) run at
+// ~500 TFLOP/s, latency-bound.  Latency hiding capacity is (bytes in flight per CU) x (FLOP per
+// byte of tile).  A 256 x 256 tile doubles the FLOP per byte (128), and K-tiles of 64 BYTES per
+// row (32 bf16) make a stage 32 KiB, so a 4-stage LDS ring (128 KiB) keeps THREE tiles = 96 KiB
+// in flight per CU: 3x the capacity.  The ring needs counted waits: `s_waitcnt vmcnt(8)` (two
+// younger stages x 4 LDS-DMA instructions per lane stay in flight across the barrier) and a raw
+// `s_barrier` -- a __syncthreads() would drain the LDS-DMA queue (vmcnt(0)).
+//
+// One barrier per stage does double duty: (RAW) every wave has waited for its own pieces of
+// stage t before arriving, so after the barrier all of stage t is in LDS; (WAR) every wave has
+// finished reading stage t-1 (its MFMAs consumed the fragments), so the DMA of stage t+3 may
+// overwrite that buffer.
+//
+// LDS image per operand tile: [256 rows][4 pieces of 16 B]; piece c of row r at position c ^ f(r)
+// with f = 0,0,3,3 over (r >> 2) & 3 (activations) / (r >> 4) & 3 (interleaved weight rows): the
+// 16 rows of one ds_read_b128 lane group then hit 16 distinct 16-byte slots of the 256-byte bank row.
+// =================================================================================================
+constexpr int BM2 = 256, BN2 = 256, ROW2 = 64, THREADS2 = 512, NSTAGE2 = 4;
+constexpr int OPER2 = 256 * ROW2;      // 16 KiB per operand per stage
+constexpr int STAGE2 = 2 * OPER2;      // 32 KiB per stage
+
+__device__ __forceinline__ int swz2(int a) { return ((a >> 1) & 1) * 3; }
+__device__ __forceinline__ int swz2_x(int row) { return swz2((row >> 2) & 3); }
+__device__ __forceinline__ int swz2_w(int row) { return swz2((row >> 4) & 3); }
+
+// XCD-aware, L2-friendly tile order shared by both kernels: each XCD owns a contiguous range of
+// logical ids; inside it n-tiles are visited in groups of `GN` with the m-tile index in between,
+// so the workgroups that run together on one XCD share a few activation tiles AND a few weight
+// tiles (both then come out of that XCD's 4 MiB L2).
+__device__ __forceinline__ void tile_of_block(uint32_t bid, uint32_t nb, uint32_t tiles_m, uint32_t tiles_n,
+                                              uint32_t& tile_m, uint32_t& tile_n) {
+  const uint32_t q8 = nb >> 3, r8 = nb & 7;
+  const uint32_t xcd = bid & 7, idx = bid >> 3;
+  const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  constexpr uint32_t GN = 8;
+  const uint32_t full = (tiles_n / GN) * GN;          // n-tiles covered by complete groups
+  const uint32_t per_group = GN * tiles_m;
+  if (logical < (full / GN) * per_group) {
+    const uint32_t grp = logical / per_group, rem = logical - grp * per_group;
+    tile_m = rem / GN;
+    tile_n = grp * GN + (rem - tile_m * GN);
+  } else {                                             // last, narrower group
+    const uint32_t rem = logical - (full / GN) * per_group, gw = tiles_n - full;
+    tile_m = rem / gw;
+    tile_n = full + (rem - tile_m * gw);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256(const LinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  uint32_t tile_m, tile_n;
+  tile_of_block(blockIdx.x, (uint32_t)p.n_blocks, (uint32_t)(p.n_blocks / p.tiles_n), (uint32_t)p.tiles_n, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM2;
+  const int n0 = (int)tile_n * BN2;
+
+  const char* src_x[2];
+  const char* src_w[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int id = r * THREADS2 + tid;
+    const int row = id >> 2, c = id & 3;
+    int64_t gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + row;
+    gn = gn < p.N ? gn : p.N - 1;
+    src_x[r] = p.A + gm * p.lda_b + ((c ^ swz2_x(row)) << 4);
+    src_w[r] = p.W + (int64_t)gn * p.ldw_b + ((c ^ swz2_w(row)) << 4);
+  }
+  auto stage = [&](int kt) {
+    const int64_t koff = (int64_t)kt * ROW2;
+    char* base = smem + (kt & (NSTAGE2 - 1)) * STAGE2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int off = (r * THREADS2 + wave * 64) * 16;  // wave-uniform; hardware adds lane * 16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[r] + koff),
+                                       (lds_ptr_t)(base + off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
+                                       (lds_ptr_t)(base + OPER2 + off), 16, 0, 0);
+    }
+  };
+
+  const int i16 = lane & 15, g = lane >> 4;
+  int off_x[8], off_w[4];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const int row = wm * 128 + 16 * f + i16;
+    off_x[f] = row * ROW2 + ((g ^ swz2_x(row)) << 4);
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int row = wn * 64 + 16 * (i16 >> 2) + 4 * f + (i16 & 3);
+    off_w[f] = OPER2 + row * ROW2 + ((g ^ swz2_w(row)) << 4);
+  }
+
+  f32x4 acc[4][8];  // [fn][fm]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Software pipeline (nt is even: K * sizeof(T) is a multiple of 128 bytes):
+  //   LDS ring   : stages kt+2 .. kt+4 in flight while stage kt is multiplied
+  //   registers  : the fragments of stage kt+1 are read from LDS while the 32 MFMAs of stage kt
+  //                run on the other fragment set -- the matrix pipe never waits for a ds_read.
+  const int nt = p.k_tiles;
+  auto read_frags = [&](int kt, u32x4 (&fw)[4], u32x4 (&fx)[8]) {
+    const char* buf = smem + (kt & (NSTAGE2 - 1)) * STAGE2;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fw[f] = *reinterpret_cast<const u32x4*>(buf + off_w[f]);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) fx[f] = *reinterpret_cast<const u32x4*>(buf + off_x[f]);
+  };
+  // One pipeline step.  Order matters: the first MFMAs of stage kt need only registers (their
+  // ds_reads were issued a whole step ago, so the compiler's lgkmcnt(0) in front of them is free);
+  // then stage kt+1 is made visible (counted vmcnt + raw barrier), the ring is refilled and the
+  // fragments of stage kt+1 are requested; the remaining MFMAs of stage kt cover that latency.
+  auto mma_rows = [&](u32x4 (&cw)[4], u32x4 (&cx)[8], int fm_lo, int fm_hi) {
+#pragma unroll
+    for (int fm = fm_lo; fm < fm_hi; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = Mma<T>::run(cw[fn], cx[fm], acc[fn][fm]);
+  };
+  auto step = [&](int kt, u32x4 (&cw)[4], u32x4 (&cx)[8], u32x4 (&nw)[4], u32x4 (&nx)[8]) {
+    mma_rows(cw, cx, 0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    // my pieces of stage kt+1 have landed once only the two younger stages remain outstanding
+    if (kt + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // RAW: stage kt+1 complete.  WAR: everyone has read stage kt.
+    asm volatile("" ::: "memory");
+    if (kt + 4 < nt) stage(kt + 4);  // into stage kt's buffer
+    read_frags(kt + 1, nw, nx);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_rows(cw, cx, 2, 8);
+  };
+
+  stage(0);
+  stage(1);  // nt >= 2
+  if (nt > 2) stage(2);
+  if (nt > 3) stage(3);
+  if (nt > 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  u32x4 fwA[4], fxA[8], fwB[4], fxB[8];
+  read_frags(0, fwA, fxA);
+  for (int kt = 0; kt + 2 < nt; kt += 2) {
+    step(kt, fwA, fxA, fwB, fxB);
+    step(kt + 1, fwB, fxB, fwA, fxA);
+  }
+  step(nt - 2, fwA, fxA, fwB, fxB);  // fetches the last stage
+  mma_rows(fwB, fxB, 0, 8);
+
+  // ---- epilogue (same ownership as the 128 x 128 kernel: a row x 16 consecutive features) ----
+  const int nbase = n0 + wn * 64 + 16 * g;
+  const int n_left = p.N - nbase;
+  if (n_left <= 0) return;
+  float bias_v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) bias_v[t] = (p.bias && t < n_left) ? p.bias[nbase + t] : 0.f;
+  const bool vec = p.vec_store != 0;
+  typedef typename Other<T>::type T2;
+#pragma unroll
+  for (int fm = 0; fm < 8; ++fm) {
+    const int64_t m = m0 + wm * 128 + 16 * fm + i16;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
+      v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
+      v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
+      v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
+    }
+    if (p.act == AURORA_ACT_GELU) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = gelu_for<T>(v[t]);
     } else if (p.act == AURORA_ACT_SILU) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
@@ -277,37 +492,43 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
   AURORA_CHECK_ARG(C != nullptr && ldc >= N && (!C2 || ldc2 >= N) && (!residual || ldr >= N || ldr == 0),
                    "linear: bad output strides");
 
+  // Big backbone shapes take the 256 x 256 ring kernel; everything else the 128 x 128 one.
+  const bool big = M >= 1024 && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
+  const int bm = big ? BM2 : BM, bn = big ? BN2 : BN, rowb = big ? ROW2 : ROW_BYTES;
   LinearArgs p;
   p.A = (const char*)A; p.lda_b = lda * es;
   p.W = (const char*)W; p.ldw_b = ldw * es;
   p.bias = bias;
   p.C = (char*)C; p.ldc = ldc; p.C2 = (char*)C2; p.ldc2 = ldc2;
   p.res = residual; p.ldr = ldr;
-  p.M = M; p.N = N; p.k_tiles = (int)(((int64_t)K * es) / ROW_BYTES); p.act = act;
-  p.tiles_n = (N + BN - 1) / BN;
-  p.n_blocks = ((M + BM - 1) / BM) * p.tiles_n;
+  p.M = M; p.N = N; p.k_tiles = (int)(((int64_t)K * es) / rowb); p.act = act;
+  p.tiles_n = (N + bn - 1) / bn;
+  p.n_blocks = ((M + bm - 1) / bm) * p.tiles_n;
   bool vec = ((uintptr_t)C % 16) == 0 && (ldc * es) % 16 == 0;
   if (C2) vec = vec && ((uintptr_t)C2 % 16) == 0 && (ldc2 * es2) % 16 == 0;
   if (residual) vec = vec && ((uintptr_t)residual % 16) == 0 && (ldr * 4) % 16 == 0;
   p.vec_store = vec ? 1 : 0;
   AURORA_CHECK_ARG(p.n_blocks < (int64_t)1 << 31, "linear: too many tiles");
 
-  const size_t lds = 4 * TILE_BYTES;
-  dim3 grid((unsigned)p.n_blocks), block(THREADS);
-  if (dtype == AURORA_F32) {
-    static bool attr_f = false;
-    if (!attr_f) {
-      (void)hipFuncSetAttribute((const void*)linear_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_f = true;
-    }
-    hipLaunchKernelGGL(linear_kernel<float>, grid, block, lds, as_stream(stream), p);
+  dim3 grid((unsigned)p.n_blocks);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)linear_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    (void)hipFuncSetAttribute((const void*)linear_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    attr_done = true;
+  }
+  if (big) {
+    if (dtype == AURORA_F32)
+      hipLaunchKernelGGL(linear_kernel_256<float>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    else
+      hipLaunchKernelGGL(linear_kernel_256<bf16_t>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
   } else {
-    static bool attr_b = false;
-    if (!attr_b) {
-      (void)hipFuncSetAttribute((const void*)linear_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_b = true;
-    }
-    hipLaunchKernelGGL(linear_kernel<bf16_t>, grid, block, lds, as_stream(stream), p);
+    if (dtype == AURORA_F32)
+      hipLaunchKernelGGL(linear_kernel<float>, grid, dim3(THREADS), 4 * TILE_BYTES, as_stream(stream), p);
+    else
+      hipLaunchKernelGGL(linear_kernel<bf16_t>, grid, dim3(THREADS), 4 * TILE_BYTES, as_stream(stream), p);
   }
   return check_launch("linear");
 }

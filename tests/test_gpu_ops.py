@@ -37,7 +37,9 @@ def relerr(a, b):
 # linear
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K", [(300, 80, 160), (128, 128, 32), (1, 512, 64), (1000, 100, 96),
-                                   (257, 1536, 512), (64, 27, 1408)])
+                                   (257, 1536, 512), (64, 27, 1408),
+                                   # >= 1024 rows and N % 256 == 0: the 256 x 256 ring kernel
+                                   (1030, 256, 32), (2050, 512, 160), (1279, 768, 64)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_linear_fp32(M, N, K, act):
     L = lib()
@@ -57,7 +59,9 @@ def test_linear_fp32(M, N, K, act):
         assert torch.isnan(out[:, N:]).all()  # padding columns untouched
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (130, 64, 64), (1000, 1536, 512), (129, 80, 2048)])
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (130, 64, 64), (1000, 1536, 512), (129, 80, 2048),
+                                   # the 256 x 256 ring kernel: 2, 4, 6 and 32 stages, ragged M
+                                   (1030, 256, 64), (1500, 512, 128), (1100, 768, 192), (4099, 1536, 1024)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_linear_bf16(M, N, K, act):
     L = lib()
@@ -71,7 +75,8 @@ def test_linear_bf16(M, N, K, act):
     out2 = torch.zeros((M, N), device=DEV)
     L.linear(a.to(DEV), w.to(DEV), b.float().to(DEV), out, out2=out2, residual=r.float().to(DEV), act=act)
     torch.cuda.synchronize()
-    assert relerr(out2, ref) < 5e-6           # fp32 copy: exact products, fp32 accumulation
+    # fp32 copy: exact products, fp32 accumulation; the bf16 kernel's GELU uses a 4e-7-accurate erf
+    assert relerr(out2, ref) < (5e-6 if act == 0 else 2e-5)
     assert relerr(out.float(), ref) < 5e-3    # bf16 copy: one rounding
 
 

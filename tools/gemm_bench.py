@@ -1,0 +1,44 @@
+"""Per-shape throughput of aurora_hip_linear on the backbone GEMM shapes of the 0.25-degree config."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from aurora_amd.engine import lib  # noqa: E402
+
+SHAPES = [  # (name, M, N, K, weight in the step)
+    ("s0.qkv", 259200, 1536, 512, 12), ("s0.proj", 259200, 512, 512, 12),
+    ("s0.fc1", 259200, 2048, 512, 12), ("s0.fc2", 259200, 512, 2048, 12),
+    ("s1.qkv", 64800, 3072, 1024, 20), ("s1.proj", 64800, 1024, 1024, 20),
+    ("s1.fc1", 64800, 4096, 1024, 20), ("s1.fc2", 64800, 1024, 4096, 20),
+    ("s2.qkv", 16200, 6144, 2048, 16), ("s2.proj", 16200, 2048, 2048, 16),
+    ("s2.fc1", 16200, 8192, 2048, 16), ("s2.fc2", 16200, 2048, 8192, 16),
+    ("sq4096", 4096, 4096, 4096, 0), ("sq8192", 8192, 8192, 8192, 0),
+]
+dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
+if len(sys.argv) > 2:  # restrict to the named shapes
+    SHAPES = [s_ for s_ in SHAPES if s_[0] in sys.argv[2].split(",")]
+tot_ms = tot_fl = 0.0
+for name, M, N, K, wt in SHAPES:
+    a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dtype)
+    w = ((torch.rand(N, K, device="cuda") * 2 - 1) * K ** -0.5).to(dtype)
+    b = torch.rand(N, device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    for _ in range(2):
+        lib.linear(a, w, b, out)
+    torch.cuda.synchronize()
+    reps = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.linear(a, w, b, out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = 2.0 * M * N * K
+    tot_ms += ms * wt
+    tot_fl += fl * wt
+    print(f"{name:8s} M={M:6d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
+    del a, w, out
+print(f"weighted backbone: {tot_ms:.1f} ms/step, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
