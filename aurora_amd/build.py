@@ -44,8 +44,10 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
     procs = []
     for src in SOURCES:
         obj = LIB.parent / (src.replace(".hip", ".o"))
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", str(CSRC / src),
-               "-o", str(obj)]
+        # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950 has one unified file);
+        # otherwise the softmax in the attention kernel pays a v_accvgpr_read per score.
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm",
+               "-amdgpu-mfma-vgpr-form=1", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

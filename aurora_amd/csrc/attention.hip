@@ -10,14 +10,19 @@
 //
 // bf16 kernel (the hot one, HBM-bound: 4 * 144 * 64 * 2 B = 72 KiB of traffic per workgroup
 // against ~10.6 MFLOP): 3 waves, wave w owns query tiles {w, w+3, w+6} of 16 queries.
-//   * K is staged row-major in LDS (128 B rows, 16-byte pieces XOR-swizzled by row & 7),
-//     V is staged TRANSPOSED (Vt[d][key]), Q fragments come straight from global memory.
+//   * K and V are staged row-major in LDS (128 B rows, 16-byte pieces XOR-swizzled by row & 7),
+//     Q fragments come straight from global memory; all 18 16-byte loads of a thread are issued
+//     before anything waits.
 //   * S^T = K Q^T with v_mfma_f32_16x16x32_bf16: the C fragment then gives every lane ONE
 //     query (lane & 15) and the keys 16*kt + 4*(lane>>4) + r.  The softmax row reduction is 36
 //     in-lane values + two xor-shuffles (lanes l, l^16, l^32, l^48 share a query).
 //   * That same register layout IS the B operand of v_mfma_f32_16x16x16_bf16 for
 //     O^T = V^T P^T (k-slot 4g + j <-> key 16*kt + 4g + j), so P never leaves registers and
-//     144 = 9 * 16 needs no key padding.  The A operand is an 8-byte read of Vt.
+//     144 = 9 * 16 needs no key padding.  The A operand (V^T) comes out of the row-major V image
+//     through gfx950's transposing LDS read ds_read_b64_tr_b16 -- no transposed copy of V exists.
+//   * The kernel was VALU-bound before it was HBM-bound (4.2 k VALU instructions per wave in the
+//     first version): conversions use v_cvt_pk_bf16_f32, the softmax runs in the exp2 domain with the
+//     1/8 scale folded into one FMA per score, and the -100 mask is skipped for single-group windows.
 //   * O^T's C fragment holds 4 consecutive d per lane and query: 8-byte stores to token order.
 //
 // fp32 kernel (exact-parity path for fp32 models): one thread per query, K/V broadcast from
@@ -32,7 +37,6 @@ namespace {
 constexpr int HD = 64;          // head dim
 constexpr int MAXN = 144;       // max tokens per window
 constexpr int MAXT = MAXN / 16; // 9 tiles of 16
-constexpr int VT_STRIDE = 148;  // elements per Vt row (296 B: 8-byte aligned, off the 256 B bank period)
 
 struct AttnArgs {
   const void* qkv; const float* bias; void* out;
@@ -43,143 +47,196 @@ struct AttnArgs {
 typedef short bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
+constexpr float LOG2E = 1.4426950408889634f;
+
+// FULL: the window has exactly 144 tokens (every stage of the published 0.25 / 0.1 / 0.4 degree
+// configurations): tile counts become compile-time constants.
+template <bool FULL>
 __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[MAXN * 128 + HD * VT_STRIDE * 2 + MAXN * 4 + MAXN + 16];
-  char* const s_k = smem;                                            // [144][128 B], swizzled
-  bf16_t* const s_vt = reinterpret_cast<bf16_t*>(smem + MAXN * 128);  // [64][VT_STRIDE]
-  int32_t* const s_tok = reinterpret_cast<int32_t*>(smem + MAXN * 128 + HD * VT_STRIDE * 2);
+  __shared__ __attribute__((aligned(16))) char smem[2 * MAXN * 128 + MAXN * 4 + MAXN + 16];
+  char* const s_k = smem;                 // [144][128 B], 16-byte pieces XOR-swizzled by row & 7
+  char* const s_v = smem + MAXN * 128;    // same image for V; transposed on READ (ds_read_b64_tr_b16)
+  int32_t* const s_tok = reinterpret_cast<int32_t*>(smem + 2 * MAXN * 128);
   uint8_t* const s_grp = reinterpret_cast<uint8_t*>(s_tok + MAXN);
 
   const int tid = threadIdx.x;
-  const int N = p.N, nt = (N + 15) >> 4;
+  const int N = FULL ? MAXN : p.N, nt = FULL ? MAXT : (N + 15) >> 4;
   const int h = blockIdx.x % p.heads;
   const int w = (blockIdx.x / p.heads) % p.n_windows;
   const int b = blockIdx.x / (p.heads * p.n_windows);
-  const bool masked = p.grp != nullptr;
 
+  // Token / group tables of this window; the -100 mask only matters if the window really mixes groups.
+  int differs = 0;
   if (tid < MAXN) {
     s_tok[tid] = tid < N ? p.tok[(int64_t)w * N + tid] : -2;
-    s_grp[tid] = (masked && tid < N) ? p.grp[(int64_t)w * N + tid] : 0;
+    int gv = 0;
+    if (p.grp && tid < N) {
+      gv = p.grp[(int64_t)w * N + tid];
+      differs = gv != p.grp[(int64_t)w * N];
+    }
+    s_grp[tid] = (uint8_t)gv;
   }
-  __syncthreads();
+  const bool masked = __syncthreads_or(differs) != 0;
 
   const bf16_t* const qkv = reinterpret_cast<const bf16_t*>(p.qkv) + (int64_t)b * p.L * 3 * p.D;
   const int D3 = 3 * p.D;
   const int col_q = h * HD, col_k = p.D + h * HD, col_v = 2 * p.D + h * HD;
 
-  // 16 bytes (8 bf16) of row `t`'s column block starting at `col`; bias for padded rows.
-  auto fetch = [&](int t, int col) -> u32x4 {
-    if (t >= 0) return *reinterpret_cast<const u32x4*>(qkv + (int64_t)t * D3 + col);
-    if (t == -1) {
-      float v[8];
-      if (p.bias) load8(p.bias + col, v);
-      else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      }
-      return u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  // 16 bytes (8 bf16) of row `t`'s column block starting at `col`.  Loads are issued unconditionally
+  // (clamped row) so that all of a thread's loads are in flight together; padded rows (t == -1: bias,
+  // what Linear(0) yields) and rows beyond the window (t == -2: zeros) are patched afterwards.
+  auto issue = [&](int t, int col) -> u32x4 {
+    return *reinterpret_cast<const u32x4*>(qkv + (int64_t)(t < 0 ? 0 : t) * D3 + col);
+  };
+  auto patch = [&](u32x4 v, int t, int col) -> u32x4 {
+    if (t >= 0) return v;
+    if (t == -1 && p.bias) {
+      float bb[8];
+      load8(p.bias + col, bb);
+      return u32x4{pack_bf16x2(bb[0], bb[1]), pack_bf16x2(bb[2], bb[3]), pack_bf16x2(bb[4], bb[5]), pack_bf16x2(bb[6], bb[7])};
     }
     return u32x4{0u, 0u, 0u, 0u};
   };
 
-  // ---- stage K (row-major, swizzled) and V (transposed) ----
-  for (int idx = tid; idx < nt * 16 * 8; idx += 192) {
-    const int row = idx >> 3, c = idx & 7;
-    const int t = s_tok[row];
-    const u32x4 kv = fetch(t, col_k + c * 8);
-    *reinterpret_cast<u32x4*>(s_k + row * 128 + ((c ^ (row & 7)) << 4)) = kv;
-    const u32x4 vv = fetch(t, col_v + c * 8);
-    bf16_t* dst = s_vt + (c * 8) * VT_STRIDE + row;
-    dst[0 * VT_STRIDE] = (bf16_t)(vv.x & 0xffff); dst[1 * VT_STRIDE] = (bf16_t)(vv.x >> 16);
-    dst[2 * VT_STRIDE] = (bf16_t)(vv.y & 0xffff); dst[3 * VT_STRIDE] = (bf16_t)(vv.y >> 16);
-    dst[4 * VT_STRIDE] = (bf16_t)(vv.z & 0xffff); dst[5 * VT_STRIDE] = (bf16_t)(vv.z >> 16);
-    dst[6 * VT_STRIDE] = (bf16_t)(vv.w & 0xffff); dst[7 * VT_STRIDE] = (bf16_t)(vv.w >> 16);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+
+  // ---- issue every global load of this thread: 6 K + 6 V pieces, then its Q fragments ----
+  constexpr int PIECES = MAXN * 8 / 192;
+  u32x4 kreg[PIECES], vreg[PIECES];
+  int trow[PIECES];
+#pragma unroll
+  for (int it = 0; it < PIECES; ++it) {
+    const int idx = tid + it * 192, row = idx >> 3, c = idx & 7;
+    trow[it] = (FULL || row < nt * 16) ? s_tok[row] : -3;  // -3: row not staged at all
+    if (trow[it] != -3) {
+      kreg[it] = issue(trow[it], col_k + c * 8);
+      vreg[it] = issue(trow[it], col_v + c * 8);
+    }
+  }
+  u32x4 qreg[3][2];
+  int tq_of[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int qt = wave + 3 * j;
+    tq_of[j] = qt < nt ? s_tok[qt * 16 + i16] : -2;
+    if (qt < nt) {
+      qreg[j][0] = issue(tq_of[j], col_q + g * 8);
+      qreg[j][1] = issue(tq_of[j], col_q + 32 + g * 8);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < PIECES; ++it) {
+    if (trow[it] == -3) continue;
+    const int idx = tid + it * 192, row = idx >> 3, c = idx & 7;
+    const int off = row * 128 + ((c ^ (row & 7)) << 4);
+    *reinterpret_cast<u32x4*>(s_k + off) = patch(kreg[it], trow[it], col_k + c * 8);
+    *reinterpret_cast<u32x4*>(s_v + off) = patch(vreg[it], trow[it], col_v + c * 8);
   }
   __syncthreads();
 
-  const int lane = tid & 63, wave = tid >> 6;
-  const int i16 = lane & 15, g = lane >> 4;
+  // Per-lane LDS offsets.  K fragment (A operand of S^T = K Q^T): row 16*kt + i16, piece g + 4*ks.
+  const int koff0 = i16 * 128 + ((g ^ (i16 & 7)) << 4), koff1 = i16 * 128 + (((g + 4) ^ (i16 & 7)) << 4);
+  // V^T fragment (A operand of O^T = V^T P^T) through the transposing read: within a 16-lane group,
+  // lane 4*r + q supplies the 8 bytes V[key 4g + r][16*dt + 4q .. +3]; lane c receives column c.
+  int voff[4];
+  {
+    const int key = 4 * g + (i16 >> 2), q = i16 & 3;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      voff[dt] = key * 128 + (((2 * dt + (q >> 1)) ^ (key & 7)) << 4) + (q & 1) * 8;
+  }
   bf16_t* const out = reinterpret_cast<bf16_t*>(p.out) + (int64_t)b * p.L * p.D;
+  const float c_scale = 0.125f * LOG2E;  // 1/sqrt(64), in the exp2 domain
 
-  for (int qt = wave; qt < nt; qt += 3) {
-    const int qi = qt * 16 + i16;
-    const int tq = s_tok[qi];  // -2 beyond N
-    const int gq = s_grp[qi];
-    u32x4 qf[2];
-    qf[0] = fetch(tq, col_q + g * 8);
-    qf[1] = fetch(tq, col_q + 32 + g * 8);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int qt = wave + 3 * j;
+    if (qt >= nt) break;
+    const int tq = tq_of[j];  // -2 beyond N
+    const u32x4 qf0 = patch(qreg[j][0], tq, col_q + g * 8), qf1 = patch(qreg[j][1], tq, col_q + 32 + g * 8);
 
     // ---- S^T tiles: keys along registers, this lane's query along lanes ----
     f32x4 st[MAXT];
 #pragma unroll
     for (int kt = 0; kt < MAXT; ++kt) {
       st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt < nt) {
-        const int row = kt * 16 + i16;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int c = g + 4 * ks;
-          const u32x4 kf = *reinterpret_cast<const u32x4*>(s_k + row * 128 + ((c ^ (row & 7)) << 4));
-          st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf),
-                                                           __builtin_bit_cast(bf16x8_t, qf[ks]), st[kt], 0, 0, 0);
-        }
+      if (FULL || kt < nt) {
+        const u32x4 k0 = *reinterpret_cast<const u32x4*>(s_k + kt * 2048 + koff0);
+        const u32x4 k1 = *reinterpret_cast<const u32x4*>(s_k + kt * 2048 + koff1);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0),
+                                                         __builtin_bit_cast(bf16x8_t, qf0), st[kt], 0, 0, 0);
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1),
+                                                         __builtin_bit_cast(bf16x8_t, qf1), st[kt], 0, 0, 0);
       }
     }
 
-    // ---- scale, mask, softmax over the 144 keys of this lane's query ----
-    float mx = -INFINITY;
+    // ---- softmax over the keys of this lane's query, in the exp2 domain ----
+    if (masked) {
+      const uint32_t gq4 = (uint32_t)s_grp[qt * 16 + i16] * 0x01010101u;
 #pragma unroll
-    for (int kt = 0; kt < MAXT; ++kt) {
-      if (kt < nt) {
-        const int k0 = kt * 16 + 4 * g;
-        const uint32_t gk4 = *reinterpret_cast<const uint32_t*>(s_grp + k0);
-        float s[4] = {st[kt].x, st[kt].y, st[kt].z, st[kt].w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[r] * 0.125f;
-          if (masked && (int)((gk4 >> (8 * r)) & 0xff) != gq) v += -100.0f;
-          if (k0 + r >= N) v = -INFINITY;
-          s[r] = v;
-          mx = fmaxf(mx, v);
+      for (int kt = 0; kt < MAXT; ++kt) {
+        if (FULL || kt < nt) {
+          const uint32_t x = *reinterpret_cast<const uint32_t*>(s_grp + kt * 16 + 4 * g) ^ gq4;
+          st[kt].x += (x & 0x000000ffu) ? -100.0f * 8.0f : 0.f;  // pre-scale: multiplied by 1/8 below
+          st[kt].y += (x & 0x0000ff00u) ? -100.0f * 8.0f : 0.f;
+          st[kt].z += (x & 0x00ff0000u) ? -100.0f * 8.0f : 0.f;
+          st[kt].w += (x & 0xff000000u) ? -100.0f * 8.0f : 0.f;
         }
-        st[kt] = f32x4{s[0], s[1], s[2], s[3]};
       }
     }
+    if (!FULL && N < nt * 16) {  // keys beyond the window in the last tile
+      const int kt = nt - 1, k0 = kt * 16 + 4 * g;
+#pragma unroll
+      for (int t2 = 0; t2 < MAXT; ++t2)
+        if (t2 == kt) {
+          if (k0 + 0 >= N) st[t2].x = -INFINITY;
+          if (k0 + 1 >= N) st[t2].y = -INFINITY;
+          if (k0 + 2 >= N) st[t2].z = -INFINITY;
+          if (k0 + 3 >= N) st[t2].w = -INFINITY;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < MAXT; ++kt)
+      if (FULL || kt < nt) mx = fmaxf(fmaxf(mx, fmaxf(st[kt].x, st[kt].y)), fmaxf(st[kt].z, st[kt].w));
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mxs = mx * c_scale;
     float sum = 0.f;
-    bf16x4_t pk[MAXT];
+    u32x2 pk[MAXT];  // packed bf16 probabilities, kept as dwords (bit-cast at the MFMA)
 #pragma unroll
     for (int kt = 0; kt < MAXT; ++kt) {
-      if (kt < nt) {
-        const float e0 = __expf(st[kt].x - mx), e1 = __expf(st[kt].y - mx);
-        const float e2 = __expf(st[kt].z - mx), e3 = __expf(st[kt].w - mx);
+      if (FULL || kt < nt) {
+        const float e0 = __builtin_amdgcn_exp2f(fmaf(st[kt].x, c_scale, -mxs));
+        const float e1 = __builtin_amdgcn_exp2f(fmaf(st[kt].y, c_scale, -mxs));
+        const float e2 = __builtin_amdgcn_exp2f(fmaf(st[kt].z, c_scale, -mxs));
+        const float e3 = __builtin_amdgcn_exp2f(fmaf(st[kt].w, c_scale, -mxs));
         sum += (e0 + e1) + (e2 + e3);
-        const uint32_t lo = pack_bf16x2(e0, e1), hi = pack_bf16x2(e2, e3);
-        pk[kt] = __builtin_bit_cast(bf16x4_t, u32x2{lo, hi});
+        pk[kt] = u32x2{pack_bf16x2(e0, e1), pack_bf16x2(e2, e3)};
       } else {
-        pk[kt] = bf16x4_t{0, 0, 0, 0};
+        pk[kt] = u32x2{0u, 0u};
       }
     }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);
 
     // ---- O^T = V^T P^T, 4 d-tiles of 16 ----
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-      const bf16_t* vrow = s_vt + (dt * 16 + i16) * VT_STRIDE + 4 * g;
 #pragma unroll
       for (int kt = 0; kt < MAXT; ++kt) {
-        if (kt < nt) {
-          const u32x2 vf = *reinterpret_cast<const u32x2*>(vrow + kt * 16);
-          o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4_t, vf), pk[kt], o, 0, 0, 0);
+        if (FULL || kt < nt) {
+          const bf16x4_t vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4_t*)(s_v + kt * 2048 + voff[dt]));
+          o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, __builtin_bit_cast(bf16x4_t, pk[kt]), o, 0, 0, 0);
         }
       }
       if (tq >= 0) {
-        const float v[4] = {o.x * inv, o.y * inv, o.z * inv, o.w * inv};
-        store4(out + (int64_t)tq * p.D + col_q + dt * 16 + 4 * g, v);
+        const u32x2 packed = u32x2{pack_bf16x2(o.x * inv, o.y * inv), pack_bf16x2(o.z * inv, o.w * inv)};
+        *reinterpret_cast<u32x2*>(out + (int64_t)tq * p.D + col_q + dt * 16 + 4 * g) = packed;
       }
     }
   }
@@ -286,7 +343,10 @@ extern "C" int aurora_hip_window_attention(const void* qkv, const float* qkv_bia
   AURORA_CHECK_ARG(blocks < ((int64_t)1 << 31), "window_attention: grid too large");
   AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens};
   if (dtype == AURORA_BF16) {
-    hipLaunchKernelGGL(window_attention_bf16, dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+    if (win_tokens == MAXN)
+      hipLaunchKernelGGL(window_attention_bf16<true>, dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+    else
+      hipLaunchKernelGGL(window_attention_bf16<false>, dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
   } else {
     const size_t lds = 2 * MAXN * HD * 4 + MAXN * 4 + MAXN + 16;
     static bool attr = false;
