@@ -81,29 +81,59 @@ def build_model(device):
     return model.eval()
 
 
-def cpu_baseline(model, budget_s: float = 30.0) -> dict:
-    """Time the CPU oracle (port of the reference algorithm, fp32) on a bounded sub-grid sample."""
+CPU_SAMPLES = ((96, 192, 56.25), (180, 360, 16), (360, 720, 4))  # (H, W, full/sample tokens)
+
+
+def cpu_worker(budget_s: float, threads: int) -> None:
+    """Subprocess body: time the CPU oracle (fp32 port of the reference algorithm) on growing
+    sub-grids of the 0.25-degree workload until the time budget is used; print one JSON object."""
+    import aurora_amd
     from aurora_amd import normalisation as nz
     from oracle import aurora_oracle as oracle
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    cfg = model.config
+    torch.set_num_threads(threads)
+    with torch.device("meta"):
+        meta = aurora_amd.AuroraPretrained(autocast=True)
+        cfg = meta.config
+        shapes = {k: tuple(v.shape) for k, v in meta.state_dict().items()}
+    # Timing does not depend on the weight values: constant fill (1.3 B parameters in about a second).
+    sd = {k: torch.full(shp, 0.01) for k, shp in shapes.items()}
+    t_start = time.perf_counter()
     result = None
-    for (H, W, frac) in ((180, 360, 16), (360, 720, 4)):
+    for (H, W, frac) in CPU_SAMPLES:
         b = synthetic_batch(cfg, H, W, 1, "cpu")
         t0 = time.perf_counter()
         with torch.inference_mode():
             oracle.forward(sd, cfg, b.surf_vars, b.static_vars, b.atmos_vars, b.metadata.lat, b.metadata.lon,
                            b.metadata.time, LEVELS, 0, nz.locations, nz.scales)
         dt = time.perf_counter() - t0
-        result = {"value": 1.0 / (dt * frac), "unit": "forecast-steps/s", "cores": cores, "kind": "port",
-                  "sample": f"oracle fp32 forward on a {H}x{W} sub-grid (1/{frac} of the 720x1440 tokens) in "
-                            f"{dt:.1f} s, throughput scaled by 1/{frac}"}
-        if dt * 4.5 > budget_s:  # the next sample is 4x the tokens
+        result = {"value": 1.0 / (dt * frac), "unit": "forecast-steps/s", "cores": threads, "kind": "port",
+                  "sample": f"CPU oracle (fp32 port of the reference forward, 1.3B-parameter model) on a {H}x{W} "
+                            f"sub-grid = 1/{frac:g} of the 720x1440 tokens in {dt:.2f} s; value = that rate / {frac:g}"}
+        print(json.dumps(result), flush=True)  # keep the best completed sample even if killed later
+        if (time.perf_counter() - t_start) + dt * 4.6 > budget_s:
             break
-    return result
+
+
+def cpu_baseline(budget_s: float = 75.0) -> dict:
+    """Run `cpu_worker` in a subprocess with a hard timeout (the 256-thread GPU hosts have stalled
+    for minutes inside CPU torch ops); the last complete sample wins."""
+    import subprocess
+
+    threads = min(os.cpu_count() or 1, 64)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-worker", "--cpu-budget", "30",
+           "--cpu-threads", str(threads)]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s,
+                             env={**os.environ, "OMP_NUM_THREADS": str(threads), "HIP_VISIBLE_DEVICES": ""})
+        out = res.stdout
+    except subprocess.TimeoutExpired as e:
+        out = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if not lines:
+        return {"value": None, "unit": "forecast-steps/s", "cores": threads, "kind": "port",
+                "sample": f"no CPU sample finished within {budget_s:.0f} s"}
+    return json.loads(lines[-1])
 
 
 def main() -> None:
@@ -112,7 +142,13 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-budget", type=float, default=24.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        cpu_worker(args.cpu_budget, args.cpu_threads)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -198,7 +234,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle sample")
-            out["cpu_baseline"] = cpu_baseline(model)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
