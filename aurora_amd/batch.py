@@ -17,7 +17,7 @@ import torch
 
 from aurora_amd.normalisation import normalise_atmos_var, normalise_surf_var
 
-__all__ = ["Metadata", "Batch"]
+__all__ = ["Metadata", "Batch", "BandBatch"]
 
 
 @dataclasses.dataclass
@@ -81,7 +81,8 @@ class Batch:
     # -- elementwise utilities ------------------------------------------------------------
     def _affine(self, surf_stats, unnormalise: bool) -> "Batch":
         lv = self.metadata.atmos_levels
-        return Batch(
+        return dataclasses.replace(
+            self,
             surf_vars={
                 k: normalise_surf_var(v, k, surf_stats, unnormalise)
                 for k, v in self.surf_vars.items()
@@ -93,7 +94,6 @@ class Batch:
             atmos_vars={
                 k: normalise_atmos_var(v, k, lv, unnormalise) for k, v in self.atmos_vars.items()
             },
-            metadata=self.metadata,
         )
 
     def normalise(self, surf_stats: dict[str, tuple[float, float]]) -> "Batch":
@@ -118,15 +118,17 @@ class Batch:
             )
         cut = lambda d: {k: v[..., :-1, :] for k, v in d.items()}  # noqa: E731
         md = dataclasses.replace(self.metadata, lat=self.metadata.lat[:-1])
-        return Batch(cut(self.surf_vars), cut(self.static_vars), cut(self.atmos_vars), md)
+        return dataclasses.replace(self, surf_vars=cut(self.surf_vars), static_vars=cut(self.static_vars),
+                                   atmos_vars=cut(self.atmos_vars), metadata=md)
 
     def _fmap(self, f: Callable[[torch.Tensor], torch.Tensor]) -> "Batch":
         md = dataclasses.replace(self.metadata, lat=f(self.metadata.lat), lon=f(self.metadata.lon))
-        return Batch(
-            {k: f(v) for k, v in self.surf_vars.items()},
-            {k: f(v) for k, v in self.static_vars.items()},
-            {k: f(v) for k, v in self.atmos_vars.items()},
-            md,
+        return dataclasses.replace(
+            self,
+            surf_vars={k: f(v) for k, v in self.surf_vars.items()},
+            static_vars={k: f(v) for k, v in self.static_vars.items()},
+            atmos_vars={k: f(v) for k, v in self.atmos_vars.items()},
+            metadata=md,
         )
 
     def to(self, device: str | torch.device) -> "Batch":
@@ -203,6 +205,22 @@ class Batch:
                 rollout_step=int(ds.rollout_step.values),
             ),
         )
+
+
+@dataclasses.dataclass
+class BandBatch(Batch):
+    """A latitude band of a batch, as held by one rank of a sharded model (not in the reference).
+
+    Produced by a sharded `Aurora.forward(..., gather_output=False)` and accepted back as input, so that
+    a roll-out can stay distributed between steps.  `full_patch_rows` is the number of patch rows of the
+    whole grid; `band` the owned patch rows `[h0, h1)`.
+    """
+
+    full_patch_rows: int = 0
+    band: tuple[int, int] = (0, 0)
+
+    def crop(self, patch_size: int) -> "BandBatch":
+        return self  # a band is cut out of an already cropped grid
 
 
 def _interpolate(v, lat, lon, lat_new, lon_new) -> torch.Tensor:

@@ -42,6 +42,7 @@ struct AttnArgs {
   const void* qkv; const float* bias; void* out;
   const int32_t* tok; const uint8_t* grp;
   int B; int64_t L; int D; int heads; int n_windows; int N;
+  int64_t L_out;  // rows of `out` per batch element; tokens >= L_out (halo rows of a band) are not stored
 };
 
 typedef short bf16x4_t __attribute__((ext_vector_type(4)));
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
     for (int dt = 0; dt < 4; ++dt)
       voff[dt] = key * 128 + (((2 * dt + (q >> 1)) ^ (key & 7)) << 4) + (q & 1) * 8;
   }
-  bf16_t* const out = reinterpret_cast<bf16_t*>(p.out) + (int64_t)b * p.L * p.D;
+  bf16_t* const out = reinterpret_cast<bf16_t*>(p.out) + (int64_t)b * p.L_out * p.D;
   const float c_scale = 0.125f * LOG2E;  // 1/sqrt(64), in the exp2 domain
 
 #pragma unroll
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
           o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, __builtin_bit_cast(bf16x4_t, pk[kt]), o, 0, 0, 0);
         }
       }
-      if (tq >= 0) {
+      if (tq >= 0 && tq < p.L_out) {
         const u32x2 packed = u32x2{pack_bf16x2(o.x * inv, o.y * inv), pack_bf16x2(o.z * inv, o.w * inv)};
         *reinterpret_cast<u32x2*>(out + (int64_t)tq * p.D + col_q + dt * 16 + 4 * g) = packed;
       }
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(192) void window_attention_f32(const AttnArgs p) {
 
   if (tid >= N) return;
   const int tq = s_tok[tid];
-  if (tq < 0) return;  // padded query: its output is cropped away upstream
+  if (tq < 0 || tq >= p.L_out) return;  // padded query (cropped upstream) or a halo row of a band
   const int gq = s_grp[tid];
   float q[HD], o[HD];
 #pragma unroll
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(192) void window_attention_f32(const AttnArgs p) {
     }
   }
   const float inv = 1.0f / sum;
-  float* const op = reinterpret_cast<float*>(p.out) + ((int64_t)b * p.L + tq) * p.D + col_q;
+  float* const op = reinterpret_cast<float*>(p.out) + ((int64_t)b * p.L_out + tq) * p.D + col_q;
 #pragma unroll
   for (int c = 0; c < 16; ++c)
     *reinterpret_cast<f32x4*>(op + 4 * c) = f32x4{o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv};
@@ -331,17 +332,17 @@ using namespace aurora;
 
 extern "C" int aurora_hip_window_attention(const void* qkv, const float* qkv_bias, void* out,
                                            const int32_t* tok, const uint8_t* grp, int B, int64_t L,
-                                           int D, int heads, int n_windows, int win_tokens, int dtype,
-                                           void* stream) {
+                                           int64_t L_out, int D, int heads, int n_windows, int win_tokens,
+                                           int dtype, void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "window_attention: bad dtype");
   AURORA_CHECK_ARG(heads > 0 && D == heads * HD, "window_attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   AURORA_CHECK_ARG(win_tokens >= 1 && win_tokens <= MAXN, "window_attention: window of %d tokens (max %d)", win_tokens, MAXN);
-  AURORA_CHECK_ARG(B > 0 && n_windows > 0 && L > 0, "window_attention: empty problem");
+  AURORA_CHECK_ARG(B > 0 && n_windows > 0 && L > 0 && L_out > 0 && L_out <= L, "window_attention: empty problem");
   AURORA_CHECK_ARG(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)out % 16) == 0 && (!qkv_bias || (uintptr_t)qkv_bias % 16 == 0),
                    "window_attention: unaligned buffer");
   const int64_t blocks = (int64_t)B * n_windows * heads;
   AURORA_CHECK_ARG(blocks < ((int64_t)1 << 31), "window_attention: grid too large");
-  AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens};
+  AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens, L_out};
   if (dtype == AURORA_BF16) {
     if (win_tokens == MAXN)
       hipLaunchKernelGGL(window_attention_bf16<true>, dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);

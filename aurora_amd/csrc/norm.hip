@@ -214,7 +214,7 @@ extern "C" int aurora_hip_merge_ln(const float* x, const float* ln_w, const floa
                                    int H, int W, int D, float eps, int dtype, void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "merge_ln: bad dtype");
   AURORA_CHECK_ARG(D % 8 == 0 && 4 * D <= 4096, "merge_ln: D=%d must be a multiple of 8 with 4D <= 4096", D);
-  AURORA_CHECK_ARG(H > 1 && W > 1, "merge_ln: grid %dx%d too small", H, W);
+  AURORA_CHECK_ARG(H >= 1 && W >= 1, "merge_ln: empty grid %dx%d", H, W);  // a band may own a single (odd) row
   MergeArgs p{x, ln_w, ln_b, out, B, C, H, W, D, (H + 1) / 2, (W + 1) / 2, eps};
   const int64_t rows = (int64_t)B * C * p.H2 * p.W2;
   if (dtype == AURORA_F32)

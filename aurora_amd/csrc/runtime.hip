@@ -53,6 +53,17 @@ __global__ void copy2d_kernel(const T* __restrict__ src, int64_t lds_, T* __rest
   }
 }
 
+__global__ void gather_rows_kernel(const char* __restrict__ src, int64_t src_pitch, const int32_t* __restrict__ idx,
+                                   char* __restrict__ dst, int64_t dst_pitch, int64_t n_rows, int pieces) {
+  // one 16-byte piece per thread: dst row r = src row idx[r]
+  const int64_t total = n_rows * pieces, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / pieces, c = i - r * pieces;
+    *reinterpret_cast<u32x4*>(dst + r * dst_pitch + c * 16) =
+        *reinterpret_cast<const u32x4*>(src + (int64_t)idx[r] * src_pitch + c * 16);
+  }
+}
+
 }  // namespace
 }  // namespace aurora
 
@@ -99,4 +110,17 @@ extern "C" int aurora_hip_copy2d(const void* src, int64_t lds_, void* dst, int64
     hipLaunchKernelGGL(copy2d_kernel<bf16_t>, dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16_t*)src, lds_,
                        (bf16_t*)dst, ldd, rows, cols16);
   return check_launch("copy2d");
+}
+
+extern "C" int aurora_hip_gather_rows(const void* src, int64_t src_pitch_bytes, const int32_t* idx, void* dst,
+                                      int64_t dst_pitch_bytes, int64_t n_rows, int64_t row_bytes, void* stream) {
+  AURORA_CHECK_ARG(row_bytes % 16 == 0 && src_pitch_bytes % 16 == 0 && dst_pitch_bytes % 16 == 0 &&
+                       (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0,
+                   "gather_rows: rows must be 16-byte multiples and aligned");
+  if (n_rows <= 0 || row_bytes <= 0) return AURORA_OK;
+  const int64_t total = n_rows * (row_bytes / 16);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const char*)src,
+                     src_pitch_bytes, idx, (char*)dst, dst_pitch_bytes, n_rows, (int)(row_bytes / 16));
+  return check_launch("gather_rows");
 }

@@ -39,8 +39,8 @@ import numpy as np
 import torch
 
 from aurora_amd import normalisation
-from aurora_amd.batch import Batch, Metadata
-from aurora_amd.engine import encodings, geometry, lib
+from aurora_amd.batch import BandBatch, Batch, Metadata
+from aurora_amd.engine import encodings, geometry, lib, partition
 from aurora_amd.model.schema import DYNAMIC_VARS, LORA_ALPHA, LORA_RANK
 from aurora_amd.normalisation import level_to_str
 
@@ -50,6 +50,24 @@ BF16 = torch.bfloat16
 
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
+
+
+@dataclasses.dataclass
+class Shard:
+    """Latitude-band sharding of one forecast over `world` ranks (see engine/partition.py)."""
+
+    rank: int
+    world: int
+    group: object = None          # torch.distributed process group (None: default group)
+    gather_output: bool = True    # True: forward() returns the full fields on every rank
+
+
+@dataclasses.dataclass
+class Exchange:
+    """One halo exchange: tensors to send to / receive from peer ranks (contiguous, on the device)."""
+
+    sends: list
+    recvs: list
 
 
 class Engine:
@@ -86,6 +104,8 @@ class Engine:
         self._stat_cache: dict = {}
         self._lora_sets: "OrderedDict[object, dict]" = OrderedDict()
         self.debug_hook = None  # optional callable(tag, tensor) at stage boundaries (tools/debug_blocks.py)
+        self.shard: Optional[Shard] = getattr(model, "_shard", None)
+        self._plan_cache: dict = {}
         self._pack_static()
 
     # ---------------------------------------------------------------------------------------
@@ -360,19 +380,65 @@ class Engine:
     # ---------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, batch: Batch) -> Batch:
+        """One forecast step.  With sharding, halo exchanges run as NCCL/RCCL point-to-point groups."""
+        gen = self.step_gen(batch)
+        try:
+            req = next(gen)
+            while True:
+                self._exchange(req)
+                req = gen.send(None)
+        except StopIteration as done:
+            return done.value
+
+    def _exchange(self, req: Exchange) -> None:
+        import torch.distributed as dist
+
+        sh = self.shard
+        to_global = (lambda r: dist.get_global_rank(sh.group, r)) if sh.group is not None else (lambda r: r)
+        ops = [dist.P2POp(dist.isend, t, to_global(peer), sh.group) for peer, t in req.sends]
+        ops += [dist.P2POp(dist.irecv, t, to_global(peer), sh.group) for peer, t in req.recvs]
+        for work in dist.batch_isend_irecv(ops):
+            work.wait()  # stream-ordered: the current HIP stream waits, not the host
+
+    def step_gen(self, batch: Batch):
+        """Generator form of the step: yields `Exchange` requests (sharded mode only) and returns the
+        prediction.  `step()` drives it with RCCL; tests drive several ranks in one process."""
         model, cfg = self.model, self.cfg
         if self.is_stale():
             raise RuntimeError("model parameters changed after packing: call model._engine = None first")
         batch = model.batch_transform_hook(batch)
-        batch = batch.type(F32).crop(cfg.patch_size).to(self.device)
+        P, D = cfg.patch_size, cfg.embed_dim
+        sh = self.shard if (self.shard is not None and self.shard.world > 1) else None
+        band = None
+        if sh is not None and isinstance(batch, BandBatch):
+            band, full_rows = tuple(batch.band), batch.full_patch_rows
+            batch = batch.type(F32).to(self.device)
+        else:
+            batch = batch.type(F32).crop(cfg.patch_size).to(self.device)
+            full_rows = batch.spatial_shape[0] // P
         md = batch.metadata
         levels = tuple(md.atmos_levels)
-        P, D = cfg.patch_size, cfg.embed_dim
-        H, W = batch.spatial_shape
-        Hp, Wp = H // P, W // P
-        L = Hp * Wp
-        patch_res = (cfg.latent_levels, Hp, Wp)
         B, T = next(iter(batch.surf_vars.values())).shape[:2]
+        W = batch.spatial_shape[1]
+        Wp = W // P
+        patch_res = (cfg.latent_levels, full_rows, Wp)
+        n_enc = len(cfg.encoder_depths)
+        all_res, _ = geometry.stage_resolutions(patch_res, n_enc)
+        rows = None
+        if sh is not None:
+            assert B == 1, "latitude-band sharding runs one forecast (batch size 1) across the ranks"
+            rows = partition.band_rows(all_res, tuple(cfg.window_size), sh.world)
+            h0, h1 = rows[0][sh.rank]
+            if band is None:  # full batch given: take this rank's band (views, no copy)
+                cut = lambda d_: {k: v[..., h0 * P:h1 * P, :] for k, v in d_.items()}  # noqa: E731
+                batch = BandBatch(cut(batch.surf_vars), cut(batch.static_vars), cut(batch.atmos_vars),
+                                  dataclasses.replace(md, lat=md.lat[h0 * P:h1 * P]), full_patch_rows=full_rows,
+                                  band=(h0, h1))
+                md = batch.metadata
+            else:
+                assert band == (h0, h1), f"band {band} does not match this rank's rows {(h0, h1)}"
+        H = batch.spatial_shape[0]
+        Hp = H // P
         assert T <= cfg.max_history_size, f"{T} > {cfg.max_history_size}."
         assert md.lat.shape[0] == H and md.lon.shape[-1] == W
         assert md.lat.dtype in (torch.float32, torch.float64), f"Latitude num. unstable: {md.lat.dtype}."
@@ -392,13 +458,60 @@ class Engine:
         else:
             mark = lambda tag: None  # noqa: E731
         mark("step start")
+        self._cur_band = (full_rows, rows[0][sh.rank]) if sh is not None else None
         x_f, x_b = self._encode(batch, B, T, H, W, Hp, Wp, levels)
         mark("encoder")
-        x_cat = self._backbone(x_f, x_b, B, patch_res, md.rollout_step)
+        x_cat = yield from self._backbone(x_f, x_b, B, patch_res, md.rollout_step, rows)
         mark("backbone")
         out = self._decode(x_cat, batch, B, H, W, Hp, Wp, levels)
         mark("decoder")
+        if sh is not None and sh.gather_output:
+            out = self._gather(out, rows[0], P)
         return out
+
+    def local_band(self, batch: Batch) -> BandBatch:
+        """This rank's latitude band of a full (cropped) batch, as views."""
+        if isinstance(batch, BandBatch):
+            return batch
+        cfg, sh = self.cfg, self.shard
+        P = cfg.patch_size
+        H, W = batch.spatial_shape
+        all_res, _ = geometry.stage_resolutions((cfg.latent_levels, H // P, W // P), len(cfg.encoder_depths))
+        h0, h1 = partition.band_rows(all_res, tuple(cfg.window_size), sh.world)[0][sh.rank]
+        cut = lambda d_: {k: v[..., h0 * P:h1 * P, :] for k, v in d_.items()}  # noqa: E731
+        md = dataclasses.replace(batch.metadata, lat=batch.metadata.lat[h0 * P:h1 * P])
+        return BandBatch(cut(batch.surf_vars), cut(batch.static_vars), cut(batch.atmos_vars), md,
+                         full_patch_rows=H // P, band=(h0, h1))
+
+    def _gather(self, pred: BandBatch, rows0, P: int) -> Batch:
+        """Assemble the full fields on every rank: each rank broadcasts its band into place."""
+        import torch.distributed as dist
+
+        sh = self.shard
+        H = rows0[-1][1] * P
+        to_global = (lambda r: dist.get_global_rank(sh.group, r)) if sh.group is not None else (lambda r: r)
+
+        def gather(d_, lead):
+            out = {}
+            for k, v in d_.items():
+                full = torch.empty((*v.shape[:-2], H, v.shape[-1]), dtype=v.dtype, device=v.device)
+                for r, (a, b) in enumerate(rows0):
+                    piece = v.contiguous() if r == sh.rank else torch.empty(
+                        (*v.shape[:-2], (b - a) * P, v.shape[-1]), dtype=v.dtype, device=v.device)
+                    dist.broadcast(piece, src=to_global(r), group=sh.group)
+                    full[..., a * P:b * P, :] = piece
+                out[k] = full
+            return out
+
+        md = pred.metadata
+        lat_parts = []
+        for r, (a, b) in enumerate(rows0):
+            piece = md.lat.contiguous() if r == sh.rank else torch.empty((b - a) * P, dtype=md.lat.dtype,
+                                                                        device=md.lat.device)
+            dist.broadcast(piece, src=to_global(r), group=sh.group)
+            lat_parts.append(piece)
+        return Batch(gather(pred.surf_vars, 2), gather(pred.static_vars, 0), gather(pred.atmos_vars, 3),
+                     dataclasses.replace(md, lat=torch.cat(lat_parts)))
 
     # -- encoder ------------------------------------------------------------------------------
     def _var_desc(self, t: torch.Tensor, kind: str, name: str, levels: tuple, transform=0, comb=None) -> lib.PatchVar:
@@ -583,7 +696,18 @@ class Engine:
         return lat
 
     # -- backbone -----------------------------------------------------------------------------
-    def _backbone(self, x_f, x_b, B, patch_res, rollout_step: int):
+    def _plans(self, res, shifted: bool, rows_s):
+        """Device copies of this rank's attention plan for one block flavour (None when un-sharded)."""
+        key = (tuple(res), shifted, tuple(rows_s))
+        if key not in self._plan_cache:
+            p = partition.block_plans(tuple(res), tuple(self.cfg.window_size), shifted, tuple(rows_s))[self.shard.rank]
+            self._plan_cache[key] = dict(
+                tok=self._dev(p.tok), grp=None if p.grp is None else self._dev(p.grp), n_own=p.n_own, n_halo=p.n_halo,
+                recv=dict(p.recv), send={q: self._dev(idx) for q, idx in p.send.items()})
+        return self._plan_cache[key]
+
+    def _backbone(self, x_f, x_b, B, patch_res, rollout_step: int, rows=None):
+        """Generator: yields `Exchange` requests when sharded (`rows[stage][rank] = (h0, h1)`)."""
         cfg = self.cfg
         bf = self.bb_dtype == BF16
         T_ = self.bb_dtype
@@ -592,17 +716,42 @@ class Engine:
         attn_w = self._attn_weights(rollout_step)
         dims = cfg.stage_dims()
 
-        def run_blocks(blocks, x_f, x_b, res, final_out=None):
-            C, H, W = res
+        rank = self.shard.rank if rows is not None else 0
+
+        def local_res(stage):
+            """(C, owned rows, W) of this rank at a stage (the whole grid when un-sharded)."""
+            C, H, W = all_res[stage]
+            if rows is None:
+                return (C, H, W)
+            h0, h1 = rows[stage][rank]
+            return (C, h1 - h0, W)
+
+        def run_blocks(blocks, x_f, x_b, stage, final_out=None):
+            res = all_res[stage]
+            C, H, W = local_res(stage)
             Ls = C * H * W
             M = B * Ls
             for bi, blk in enumerate(blocks):
                 dim, heads = blk["dim"], blk["heads"]
                 a_in = x_b if bf else x_f
                 w_qkv, w_proj = attn_w[blk["prefix"]]
-                qkv = lib.linear(a_in, w_qkv, blk["qkv.b"], self.empty(M, 3 * dim, dtype=T_))
-                tok, grp = self._tables(res, blk["shifted"])
-                ao = lib.window_attention(qkv, blk["qkv.b"], self.empty(M, dim, dtype=T_), tok, grp, B, Ls, dim, heads)
+                if rows is None:
+                    qkv = lib.linear(a_in, w_qkv, blk["qkv.b"], self.empty(M, 3 * dim, dtype=T_))
+                    tok, grp = self._tables(res, blk["shifted"])
+                    ao = lib.window_attention(qkv, blk["qkv.b"], self.empty(M, dim, dtype=T_), tok, grp, B, Ls, dim,
+                                              heads)
+                else:
+                    pl = self._plans(res, blk["shifted"], rows[stage])
+                    assert pl["n_own"] == Ls
+                    qkv = self.empty(Ls + pl["n_halo"], 3 * dim, dtype=T_)
+                    lib.linear(a_in, w_qkv, blk["qkv.b"], qkv[:Ls])
+                    if pl["n_halo"]:
+                        sends = [(q, lib.gather_rows(qkv[:Ls], idx, self.empty(idx.numel(), 3 * dim, dtype=T_)))
+                                 for q, idx in pl["send"].items()]
+                        recvs = [(q, qkv[Ls + off:Ls + off + cnt]) for q, (off, cnt) in pl["recv"].items()]
+                        yield Exchange(sends, recvs)
+                    ao = lib.window_attention(qkv, blk["qkv.b"], self.empty(M, dim, dtype=T_), pl["tok"], pl["grp"],
+                                              B, Ls + pl["n_halo"], dim, heads, L_out=Ls)
                 del qkv
                 y = lib.linear(ao, w_proj, blk["proj.b"], self.empty(M, dim, dtype=T_))
                 del ao
@@ -622,12 +771,13 @@ class Engine:
 
         skips = []
         for i in range(n_enc):
-            x_f, x_b = run_blocks(by_layer("enc", i), x_f, x_b, all_res[i])
+            x_f, x_b = yield from run_blocks(by_layer("enc", i), x_f, x_b, i)
             skips.append(x_f)
             if self.debug_hook:
                 self.debug_hook(f"enc{i}", x_f)
             if i < n_enc - 1:
-                C, H, W = all_res[i]
+                assert all_res[i][1] > 1 and all_res[i][2] > 1, f"grid {all_res[i]} too small to merge"
+                C, H, W = local_res(i)
                 m = self.merges[i]
                 H2, W2 = (H + 1) // 2, (W + 1) // 2
                 M2 = B * C * H2 * W2
@@ -645,27 +795,29 @@ class Engine:
                     self.debug_hook(f"merge{i}", x_f)
 
         D0 = dims[0]
-        L0 = int(np.prod(all_res[0]))
+        L0 = int(np.prod(local_res(0)))
         x_cat = self.empty(B * L0, 2 * D0)
         for i in range(n_dec):
             idx = n_dec - 1 - i
             last_layer = i == n_dec - 1
             final_out = x_cat[:, :D0] if last_layer else None
             blocks = by_layer("dec", i)
-            x_f, x_b = run_blocks(blocks, x_f, x_b, all_res[idx], final_out=final_out)
+            x_f, x_b = yield from run_blocks(blocks, x_f, x_b, idx, final_out=final_out)
             if last_layer and not blocks:
                 lib.copy2d(x_f, x_cat[:, :D0])
             if self.debug_hook:
                 self.debug_hook(f"dec{i}", x_cat[:, :D0] if last_layer else x_f)
             if i < n_dec - 1:
-                C, H, W = all_res[idx]
+                C, H, W = local_res(idx)
                 s = self.splits[i]
                 dim = dims[idx]
                 a_in = x_b if bf else x_f
                 y1 = lib.linear(a_in, s["w1"], None, self.empty(B * C * H * W, 2 * dim, dtype=T_))
                 crop = pads[idx - 1]
+                if rows is not None and rank != len(rows[idx]) - 1:
+                    crop = (crop[0], 0, crop[2])  # the odd bottom row belongs to the last band only
                 Ho, Wo = 2 * H - crop[1], 2 * W - crop[2]
-                assert (C, Ho, Wo) == tuple(all_res[idx - 1])
+                assert (C, Ho, Wo) == tuple(local_res(idx - 1))
                 M2 = B * C * Ho * Wo
                 sp = lib.split_ln(y1, s["ln_w"], s["ln_b"], self.empty(M2, dim // 2, dtype=T_), B, C, H, W,
                                   dim // 2, crop[1], crop[2])
@@ -765,14 +917,12 @@ class Engine:
 
         surf_out = {n: out_s[i] for i, n in enumerate(surf_in)}               # (B, 1, H, W)
         atmos_out = {n: out_a[i][:, None] for i, n in enumerate(atmos_in)}    # (B, 1, C, H, W)
-        return Batch(
-            surf_out,
-            dict(batch.static_vars),
-            atmos_out,
-            Metadata(lat=md.lat.to(F32), lon=md.lon.to(F32),
-                     time=tuple(t + cfg.timestep for t in md.time), atmos_levels=md.atmos_levels,
-                     rollout_step=new_step),
-        )
+        new_md = Metadata(lat=md.lat.to(F32), lon=md.lon.to(F32), time=tuple(t + cfg.timestep for t in md.time),
+                          atmos_levels=md.atmos_levels, rollout_step=new_step)
+        if self._cur_band is not None:
+            return BandBatch(surf_out, dict(batch.static_vars), atmos_out, new_md,
+                             full_patch_rows=self._cur_band[0], band=self._cur_band[1])
+        return Batch(surf_out, dict(batch.static_vars), atmos_out, new_md)
 
     def _diff_fields(self, d, name, diff, head_names, P2, lvl_stride, prev_vars, levels, is_atmos):
         """Air-pollution difference prediction (aurora.py:761-779): fields of the descriptor."""

@@ -43,7 +43,9 @@ _SIGNATURES = {
                                   c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                   c_int, c_void_p]),
     "aurora_hip_window_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                            c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                            c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "aurora_hip_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                       c_void_p]),
     "aurora_hip_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                      c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float,
                                      c_int, c_void_p]),
@@ -205,9 +207,11 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
 
 def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], out: torch.Tensor,
                      tok: torch.Tensor, grp: Optional[torch.Tensor], B: int, L: int, D: int,
-                     heads: int) -> torch.Tensor:
+                     heads: int, L_out: Optional[int] = None) -> torch.Tensor:
+    """`L` rows of qkv per batch element ([owned | halo] for a latitude band), `L_out` rows of out."""
+    L_out = L if L_out is None else L_out
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.numel() == B * L * 3 * D
-    assert out.numel() == B * L * D and out.dtype == qkv.dtype
+    assert out.numel() == B * L_out * D and out.dtype == qkv.dtype
     assert tok.dtype == torch.int32 and tok.is_contiguous() and tok.dim() == 2
     assert grp is None or (grp.dtype == torch.uint8 and grp.shape == tok.shape and grp.is_contiguous())
     assert qkv_bias is None or (qkv_bias.dtype == torch.float32 and qkv_bias.numel() == 3 * D)
@@ -216,8 +220,8 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], out: t
     # algorithmic bytes: q, k, v read + o written once over the padded windows
     with _Timed(name, 4.0 * B * n_windows * n_tok * D * qkv.element_size()):
         _check(load().aurora_hip_window_attention(_ptr(qkv), _ptr(qkv_bias), _ptr(out), _ptr(tok), _ptr(grp),
-                                                  B, L, D, heads, n_windows, n_tok, dtype_code(qkv.dtype),
-                                                  _stream()))
+                                                  B, L, L_out, D, heads, n_windows, n_tok,
+                                                  dtype_code(qkv.dtype), _stream()))
     return out
 
 
@@ -311,6 +315,18 @@ def copy2d(src: torch.Tensor, dst: torch.Tensor, cols: Optional[int] = None) -> 
     assert src.dtype == dst.dtype and src.shape[0] == dst.shape[0]
     _check(load().aurora_hip_copy2d(_ptr(src), lds_, _ptr(dst), ldd, src.shape[0],
                                     cols if cols is not None else cs, dtype_code(src.dtype), _stream()))
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst[r] = src[idx[r]] for 2-D row-major views with equal row width (bytes multiple of 16)."""
+    lds_, w = _rows(src)
+    ldd, wd = _rows(dst)
+    assert w == wd and src.dtype == dst.dtype and idx.dtype == torch.int32 and idx.is_contiguous()
+    assert dst.shape[0] == idx.numel()
+    es = src.element_size()
+    _check(load().aurora_hip_gather_rows(_ptr(src), lds_ * es, _ptr(idx), _ptr(dst), ldd * es, idx.numel(), w * es,
+                                         _stream()))
+    return dst
 
 
 def convert(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,134 @@
+"""Latitude-band partition of the token grid and the halo plans of window attention.
+
+Strong scaling of ONE forecast over R GPUs: every rank owns a contiguous band
+of latitude rows at every backbone stage.  All operators except window attention are local to a
+token (GEMMs, LayerNorms, MLPs), to a 2x2 block (patch merge/split: band boundaries are kept on even
+rows of the finer stage) or to a grid column (patch embed, Perceiver level (de)aggregation,
+unpatchify), so they simply run on the rank's rows.
+
+Window attention needs, for every window that contains at least one owned token, the q/k/v rows of
+the window's other tokens.  Because the engine's attention kernel already gathers through a token
+table, a band needs no special kernel: its table indexes a local buffer `[own rows | halo rows]`,
+the halo rows are received from the neighbouring ranks, and outputs are written for owned tokens
+only.  Windows that straddle a boundary are evaluated on both sides (each for its own queries).
+
+The cyclic wrap of the latitude roll (last rows <-> first rows) is part of the global table and is
+handled like any other foreign token; the -100 mask separates those groups exactly as upstream.
+
+Everything here is host-side numpy, derived from `geometry.window_tables` (which is itself checked
+against the reference's roll/pad/partition chain).  tests/test_partition.py replays the plans with
+numpy attention -- in-process for several rank counts and across two gloo processes.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import math
+from functools import lru_cache
+
+import numpy as np
+
+from aurora_amd.engine import geometry
+
+Res = tuple[int, int, int]
+
+
+def band_rows(all_res: list[Res], window: Res, world: int) -> list[list[tuple[int, int]]]:
+    """Owned latitude rows `[stage][rank] -> (h0, h1)`.
+
+    Boundaries are chosen on the coarsest stage and doubled per finer stage, so 2x2 merges / splits
+    never cross a rank.  When possible the unit is chosen such that the finer stages' boundaries fall
+    on window rows (then un-shifted blocks need no halo there).
+    """
+    n = len(all_res)
+    Hc = all_res[-1][1]
+    unit = window[1] // math.gcd(window[1], 2) if n > 1 else window[1]
+    if unit < 1 or -(-Hc // unit) < world:
+        unit = 1
+    n_units = -(-Hc // unit)
+    if n_units < world:
+        raise ValueError(f"cannot split {Hc} latitude rows of the coarsest stage over {world} ranks")
+    base, extra = divmod(n_units, world)
+    bounds = [0]
+    for r in range(world):
+        bounds.append(bounds[-1] + (base + (1 if r < extra else 0)) * unit)
+    bounds = [min(b, Hc) for b in bounds]
+    bounds[-1] = Hc
+    out = []
+    for s in range(n):
+        mult = 2 ** (n - 1 - s)
+        Hs = all_res[s][1]
+        out.append([(min(bounds[r] * mult, Hs), min(bounds[r + 1] * mult, Hs) if r < world - 1 else Hs)
+                    for r in range(world)])
+    for rows in out:
+        assert all(h1 > h0 for h0, h1 in rows), "a rank ended up without rows"
+    return out
+
+
+@dataclasses.dataclass
+class BlockPlan:
+    """What rank `rank` needs to run window attention of one block flavour on its band."""
+
+    tok: np.ndarray                  # int32 [n_windows_local, N]: index into [own | halo], -1 = padding
+    grp: np.ndarray | None           # uint8 [n_windows_local, N] or None
+    n_own: int                       # owned tokens (rows of the local activation buffers)
+    n_halo: int                      # halo rows appended behind them
+    recv: dict[int, tuple[int, int]]  # peer -> (offset into the halo region, count)
+    send: dict[int, np.ndarray]      # peer -> int32 local indices of owned tokens, in the peer's halo order
+
+
+def local_index(tokens: np.ndarray, res: Res, h0: int, h1: int) -> np.ndarray:
+    """Local index (c * rows + h - h0) * W + w of global token ids that lie in rows [h0, h1)."""
+    C, H, W = res
+    c, rem = np.divmod(tokens, H * W)
+    h, w = np.divmod(rem, W)
+    return ((c * (h1 - h0) + (h - h0)) * W + w).astype(np.int64)
+
+
+@lru_cache(maxsize=256)
+def block_plans(res: Res, window: Res, shifted: bool, rows: tuple[tuple[int, int], ...]) -> tuple[BlockPlan, ...]:
+    """Plans of all ranks for one (stage resolution, block flavour); `rows[rank] = (h0, h1)`."""
+    C, H, W = res
+    world = len(rows)
+    tok_g, grp_g, _ = geometry.window_tables(res, window, shifted)
+    real = tok_g >= 0
+    h_of = (np.where(real, tok_g, 0) // W) % H
+    owner_of_row = np.empty(H, dtype=np.int64)
+    for r, (h0, h1) in enumerate(rows):
+        owner_of_row[h0:h1] = r
+    owner = np.where(real, owner_of_row[h_of], -1)  # [nW, N]
+
+    foreign_lists = []
+    plans = []
+    for r, (h0, h1) in enumerate(rows):
+        mine = (owner == r).any(axis=1)                      # windows touching the band
+        tw, ow = tok_g[mine], owner[mine]
+        gw = None if grp_g is None else np.ascontiguousarray(grp_g[mine])
+        foreign = np.unique(tw[(ow != r) & (ow >= 0)])       # sorted global ids
+        f_owner = owner_of_row[(foreign // W) % H]
+        order = np.lexsort((foreign, f_owner))               # group by owning rank, then by id
+        foreign, f_owner = foreign[order], f_owner[order]
+        n_own = C * (h1 - h0) * W
+        halo_pos = {int(t): n_own + i for i, t in enumerate(foreign)}
+        loc = np.full(tw.shape, -1, dtype=np.int64)
+        own_mask = ow == r
+        loc[own_mask] = local_index(tw[own_mask], res, h0, h1)
+        fm = (ow != r) & (ow >= 0)
+        if fm.any():
+            loc[fm] = np.vectorize(halo_pos.__getitem__, otypes=[np.int64])(tw[fm])
+        recv = {}
+        for q in np.unique(f_owner):
+            idx = np.nonzero(f_owner == q)[0]
+            recv[int(q)] = (int(idx[0]), int(len(idx)))
+        foreign_lists.append((foreign, f_owner))
+        plans.append(BlockPlan(tok=np.ascontiguousarray(loc.astype(np.int32)), grp=gw, n_own=n_own,
+                               n_halo=len(foreign), recv=recv, send={}))
+    # what I send = what my peers listed as foreign and I own, in THEIR order
+    for q, (foreign, f_owner) in enumerate(foreign_lists):
+        for r in np.unique(f_owner):
+            toks = foreign[f_owner == r]
+            h0, h1 = rows[int(r)]
+            plans[int(r)].send[q] = local_index(toks, res, h0, h1).astype(np.int32)
+    for r, p in enumerate(plans):
+        assert set(p.send) == {q for q, pq in enumerate(plans) if r in pq.recv}
+    return tuple(plans)

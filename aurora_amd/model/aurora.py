@@ -171,6 +171,7 @@ class Aurora(nn.Module):
         self.encoder.patch_size = patch_size
 
         self._engine = None  # built lazily on the first forward (aurora_amd.engine.Engine)
+        self._shard = None   # see configure_sharding()
 
     # -- the step ------------------------------------------------------------------------
     def forward(self, batch: Batch) -> Batch:
@@ -190,6 +191,19 @@ class Aurora(nn.Module):
 
             self._engine = Engine(self)
         return self._engine
+
+    def configure_sharding(self, rank: int, world_size: int, group=None, gather_output: bool = True) -> None:
+        """Run ONE forecast across `world_size` GPUs (one process per GPU): the latitude rows of the token
+        grid are split into bands, shifted-window attention exchanges halo rows with the neighbouring ranks
+        over RCCL point-to-point (aurora_amd/engine/partition.py).  Not part of the reference, which is
+        single-device.  Every rank calls `forward` with the same full `Batch`; with
+        `gather_output=True` every rank gets the full prediction back, otherwise a `BandBatch` holding its
+        own latitude band (which `forward` / `rollout` accept as the next input).
+        """
+        from aurora_amd.engine.engine import Shard
+
+        self._shard = Shard(rank, world_size, group, gather_output) if world_size > 1 else None
+        self._engine = None
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .double() / .cuda() change storage: drop packed weights.

@@ -21,6 +21,10 @@ def rollout(model, batch: Batch, steps: int) -> Generator[Batch, None, None]:
     batch = model.batch_transform_hook(batch)
     p = next(model.parameters())
     batch = batch.type(p.dtype).crop(model.patch_size).to(p.device)
+    shard = getattr(model, "_shard", None)
+    if shard is not None and not shard.gather_output:
+        # sharded model that keeps its state distributed: continue from this rank's latitude band
+        batch = model.engine().local_band(batch)
 
     for _ in range(steps):
         pred = model.forward(batch)

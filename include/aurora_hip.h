@@ -64,11 +64,14 @@ int aurora_hip_linear(const void* A, int64_t lda, const void* W, int64_t ldw, co
  * compute_3d_shifted_window_mask (swin3d.py:303-360): score += -100 where labels differ.
  * Output O: [B][L][D], token order, padded positions are not written.  head_dim must be 64.
  * Replaces WindowAttention.forward's SDPA (swin3d.py:154-168) + swin3d.py:177-285,471-505.
+ * Latitude-band sharding: a rank passes qkv = [owned rows | halo rows received from its
+ * neighbours] (L rows) and L_out = number of owned rows; outputs are written for tokens < L_out
+ * only (out has L_out rows per batch element).  Un-sharded callers pass L_out = L.
  */
 int aurora_hip_window_attention(const void* qkv, const float* qkv_bias, void* out,
                                 const int32_t* tok, const uint8_t* grp,
-                                int B, int64_t L, int D, int heads, int n_windows, int win_tokens,
-                                int dtype, void* stream);
+                                int B, int64_t L, int64_t L_out, int D, int heads, int n_windows,
+                                int win_tokens, int dtype, void* stream);
 
 /* ---- (adaptive) layer norm with residual --------------------------------------------------
  * out[r,:] = res[r % res_mod? ,:] + LN(y[r,:]) * gain[:] + shift[:]   (res nullable)
@@ -184,6 +187,10 @@ int aurora_hip_unpatchify(const float* y, int64_t ldy, const aurora_unpatch_var*
 /* dst[r, 0:cols] = src[r, 0:cols] for r < rows (row strides in elements of `dtype`). */
 int aurora_hip_copy2d(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows,
                       int64_t cols, int dtype, void* stream);
+/* dst row r = src row idx[r] (r < n_rows), rows of row_bytes bytes (multiple of 16), pitches in bytes.
+ * Packs the halo rows a latitude band sends to a neighbour (new: the reference is single-device). */
+int aurora_hip_gather_rows(const void* src, int64_t src_pitch_bytes, const int32_t* idx, void* dst,
+                           int64_t dst_pitch_bytes, int64_t n_rows, int64_t row_bytes, void* stream);
 /* dst (other dtype) = convert(src): n elements, fp32 -> bf16 (round-nearest-even) or back. */
 int aurora_hip_convert(const void* src, void* dst, int64_t n, int src_dtype, void* stream);
 

@@ -51,5 +51,5 @@ def test_argument_errors_surface_without_a_gpu(built):
     fn = shim.load().aurora_hip_linear
     code = fn(16, 40, 16, 40, None, 16, 8, None, 0, None, 0, 4, 8, 40, 0, 0, None)  # K=40 fp32: not 32-multiple
     assert code == -1 and b"multiple" in shim.load().aurora_hip_last_error()
-    code = shim.load().aurora_hip_window_attention(16, None, 16, 16, None, 1, 10, 96, 2, 1, 4, 1, None)
+    code = shim.load().aurora_hip_window_attention(16, None, 16, 16, None, 1, 10, 10, 96, 2, 1, 4, 1, None)
     assert code == -1 and b"head_dim" in shim.load().aurora_hip_last_error()

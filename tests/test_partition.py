@@ -1,0 +1,152 @@
+"""Latitude-band plans: replaying them (numpy attention on `[own | halo]` buffers, halos moved exactly as
+the send/recv lists say) reproduces global window attention; once in-process for several rank counts and
+once across two gloo processes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from aurora_amd.engine import geometry, partition
+
+WINDOW = (2, 6, 12)
+
+
+def attention_numpy(buf, tok, grp, D, heads):
+    """Per-window softmax attention on rows of `buf` ([n, 3D], q|k|v); returns {local row: output}."""
+    hd = D // heads
+    out = {}
+    for w in range(tok.shape[0]):
+        idx = tok[w]
+        rows = np.where(idx[:, None] >= 0, buf[np.maximum(idx, 0)], 0.0)  # padding: q = k = v = bias = 0 here
+        q, k, v = (rows[:, i * D:(i + 1) * D].reshape(-1, heads, hd).transpose(1, 0, 2) for i in range(3))
+        s = q @ k.transpose(0, 2, 1) / np.sqrt(hd)
+        if grp is not None:
+            s = s + np.where(grp[w][None, :, None] != grp[w][None, None, :], -100.0, 0.0)
+        s = s - s.max(-1, keepdims=True)
+        p = np.exp(s)
+        o = (p / p.sum(-1, keepdims=True)) @ v
+        o = o.transpose(1, 0, 2).reshape(-1, D)
+        for n, t in enumerate(idx):
+            if t >= 0:
+                out[int(t)] = o[n]
+    return out
+
+
+def global_attention(qkv, res, shifted, D, heads):
+    tok, grp, _ = geometry.window_tables(res, WINDOW, shifted)
+    o = attention_numpy(qkv, tok, grp, D, heads)
+    return np.stack([o[t] for t in range(qkv.shape[0])])
+
+
+def rank_inputs(qkv, res, rows_r):
+    C, H, W = res
+    h0, h1 = rows_r
+    return qkv.reshape(C, H, W, -1)[:, h0:h1].reshape(-1, qkv.shape[1])
+
+
+CASES = [((4, 24, 24), 2), ((4, 24, 24), 4), ((4, 45, 30), 3), ((4, 45, 24), 8), ((4, 13, 26), 2)]
+
+
+@pytest.mark.parametrize("res,world", CASES)
+@pytest.mark.parametrize("shifted", [False, True])
+def test_band_plans_reproduce_global_attention(res, world, shifted):
+    C, H, W = res
+    D, heads = 8, 2
+    rng = np.random.default_rng(0)
+    qkv = rng.standard_normal((C * H * W, 3 * D))
+    ref = global_attention(qkv, res, shifted, D, heads)
+    rows = partition.band_rows([res], WINDOW, world)[0]
+    assert rows[0][0] == 0 and rows[-1][1] == H and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    plans = partition.block_plans(res, WINDOW, shifted, tuple(rows))
+    own = [rank_inputs(qkv, res, rows[r]) for r in range(world)]
+    bufs = []
+    for r, p in enumerate(plans):
+        assert own[r].shape[0] == p.n_own
+        halo = np.zeros((p.n_halo, 3 * D))
+        for q, (off, cnt) in p.recv.items():
+            sent = own[q][plans[q].send[r]]            # what peer q sends to r
+            assert sent.shape[0] == cnt
+            halo[off:off + cnt] = sent
+        bufs.append(np.concatenate([own[r], halo]))
+    got = np.zeros_like(ref)
+    seen = np.zeros(C * H * W, dtype=int)
+    for r, p in enumerate(plans):
+        out = attention_numpy(bufs[r], p.tok, p.grp, D, heads)
+        h0, h1 = rows[r]
+        for loc, val in out.items():
+            if loc < p.n_own:                           # outputs only for owned tokens
+                c, rem = divmod(loc, (h1 - h0) * W)
+                hl, w_ = divmod(rem, W)
+                g = (c * H + h0 + hl) * W + w_
+                got[g] = val
+                seen[g] += 1
+    assert (seen == 1).all()
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12)
+
+
+def test_band_rows_are_merge_aligned_and_window_aligned_where_possible():
+    all_res, _ = geometry.stage_resolutions((4, 180, 360), 3)
+    rows = partition.band_rows(all_res, WINDOW, 8)
+    for r in range(8):
+        (a0, b0), (a1, b1), (a2, b2) = rows[0][r], rows[1][r], rows[2][r]
+        assert (a0, a1) == (4 * a2, 2 * a2) and b0 == min(4 * b2, 180) and b1 == min(2 * b2, 90)
+        assert a0 % 6 == 0 and a1 % 6 == 0          # window-aligned at stages 0 and 1
+    sizes = [b - a for a, b in rows[2]]
+    assert sum(sizes) == 45 and max(sizes) == 6
+    # un-shifted blocks need no halo where bands are window-aligned
+    for s in (0, 1):
+        for p in partition.block_plans(all_res[s], WINDOW, False, tuple(rows[s])):
+            assert p.n_halo == 0 and not p.send
+        # shifted blocks: 3 halo rows per neighbouring side (the cyclic wrap makes the first and the
+        # last rank neighbours as well)
+        C, _, W = all_res[s]
+        for p in partition.block_plans(all_res[s], WINDOW, True, tuple(rows[s])):
+            assert p.n_halo == 2 * 3 * C * W and len(p.send) == 2 and len(p.recv) == 2
+
+
+def _gloo_worker(rank, world, port, res, shifted, ret):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    C, H, W = res
+    D, heads = 8, 2
+    qkv = np.random.default_rng(0).standard_normal((C * H * W, 3 * D))
+    rows = partition.band_rows([res], WINDOW, world)[0]
+    p = partition.block_plans(res, WINDOW, shifted, tuple(rows))[rank]
+    own = torch.from_numpy(rank_inputs(qkv, res, rows[rank]).copy())
+    halo = torch.zeros((p.n_halo, 3 * D), dtype=torch.float64)
+    ops, keep = [], []
+    for q, idx in p.send.items():
+        t = own[torch.from_numpy(idx.astype(np.int64))].contiguous()
+        keep.append(t)
+        ops.append(dist.P2POp(dist.isend, t, q))
+    for q, (off, cnt) in p.recv.items():
+        ops.append(dist.P2POp(dist.irecv, halo[off:off + cnt], q))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    out = attention_numpy(torch.cat([own, halo]).numpy(), p.tok, p.grp, D, heads)
+    band = np.stack([out[i] for i in range(p.n_own)])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, band)
+    if rank == 0:
+        full = np.concatenate([g.reshape(C, -1, W, D) for g in gathered], axis=1).reshape(-1, D)
+        ref = global_attention(qkv, res, shifted, D, heads)
+        ret.put(float(np.abs(full - ref).max()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shifted", [False, True])
+def test_halo_exchange_over_two_gloo_processes(shifted):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = 29650 + int(shifted)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, (4, 21, 24), shifted, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=10) < 1e-10
