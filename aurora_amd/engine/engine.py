@@ -391,10 +391,25 @@ class Engine:
             return done.value
 
     def _exchange(self, req: Exchange) -> None:
+        """Carry out one halo exchange with torch.distributed point-to-point operations.
+
+        backend "nccl" (= RCCL on ROCm): device tensors go straight over xGMI, grouped into one
+        ncclGroup per exchange; the current HIP stream waits for completion, the host does not.
+        backend "gloo" (tests: several processes sharing one GPU): staged through host memory.
+        """
         import torch.distributed as dist
 
         sh = self.shard
         to_global = (lambda r: dist.get_global_rank(sh.group, r)) if sh.group is not None else (lambda r: r)
+        if dist.get_backend(sh.group) == "gloo":
+            host_recv = [(peer, t, torch.empty(t.shape, dtype=t.dtype)) for peer, t in req.recvs]
+            ops = [dist.P2POp(dist.isend, t.cpu(), to_global(peer), sh.group) for peer, t in req.sends]
+            ops += [dist.P2POp(dist.irecv, h, to_global(peer), sh.group) for peer, _, h in host_recv]
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+            for _, t, h in host_recv:
+                t.copy_(h)
+            return
         ops = [dist.P2POp(dist.isend, t, to_global(peer), sh.group) for peer, t in req.sends]
         ops += [dist.P2POp(dist.irecv, t, to_global(peer), sh.group) for peer, t in req.recvs]
         for work in dist.batch_isend_irecv(ops):
@@ -490,6 +505,15 @@ class Engine:
         sh = self.shard
         H = rows0[-1][1] * P
         to_global = (lambda r: dist.get_global_rank(sh.group, r)) if sh.group is not None else (lambda r: r)
+        staged = dist.get_backend(sh.group) == "gloo"
+
+        def bcast(piece, src):
+            if staged:
+                h = piece.cpu()
+                dist.broadcast(h, src=to_global(src), group=sh.group)
+                piece.copy_(h)
+            else:
+                dist.broadcast(piece, src=to_global(src), group=sh.group)
 
         def gather(d_, lead):
             out = {}
@@ -498,7 +522,7 @@ class Engine:
                 for r, (a, b) in enumerate(rows0):
                     piece = v.contiguous() if r == sh.rank else torch.empty(
                         (*v.shape[:-2], (b - a) * P, v.shape[-1]), dtype=v.dtype, device=v.device)
-                    dist.broadcast(piece, src=to_global(r), group=sh.group)
+                    bcast(piece, r)
                     full[..., a * P:b * P, :] = piece
                 out[k] = full
             return out
@@ -508,7 +532,7 @@ class Engine:
         for r, (a, b) in enumerate(rows0):
             piece = md.lat.contiguous() if r == sh.rank else torch.empty((b - a) * P, dtype=md.lat.dtype,
                                                                         device=md.lat.device)
-            dist.broadcast(piece, src=to_global(r), group=sh.group)
+            bcast(piece, r)
             lat_parts.append(piece)
         return Batch(gather(pred.surf_vars, 2), gather(pred.static_vars, 0), gather(pred.atmos_vars, 3),
                      dataclasses.replace(md, lat=torch.cat(lat_parts)))
@@ -745,7 +769,7 @@ class Engine:
                     assert pl["n_own"] == Ls
                     qkv = self.empty(Ls + pl["n_halo"], 3 * dim, dtype=T_)
                     lib.linear(a_in, w_qkv, blk["qkv.b"], qkv[:Ls])
-                    if pl["n_halo"]:
+                    if pl["send"] or pl["recv"]:
                         sends = [(q, lib.gather_rows(qkv[:Ls], idx, self.empty(idx.numel(), 3 * dim, dtype=T_)))
                                  for q, idx in pl["send"].items()]
                         recvs = [(q, qkv[Ls + off:Ls + off + cnt]) for q, (off, cnt) in pl["recv"].items()]

@@ -10,9 +10,12 @@ Perceiver encoder, 48 Swin blocks, Perceiver decoder, unpatchify -- nothing skip
 random (`torch.manual_seed(0)`, zero-initialised AdaLN / LoRA tensors re-randomised), inputs are
 `randn` in normalised space mapped to physical units (`torch.manual_seed(1)`).
 
-With N > 1 every rank (one process per GPU) advances its own forecast (independent initial
-conditions = ensemble members); there is no collective on the data path, `value` is the number of
-forecast steps all ranks completed divided by the slowest rank's time ("weak" scaling).
+With N > 1 (one process per GPU, RCCL) the default is STRONG scaling of one forecast: the latitude
+rows of the token grid are split into N bands (aurora_amd/engine/partition.py), shifted-window
+attention exchanges halo rows with the neighbouring ranks by RCCL point-to-point, the state stays
+distributed between steps (`gather_output=False`), `value` = steps of that one forecast per second.
+`AURORA_BENCH_MODE=replicas` instead lets every rank advance its own forecast (ensemble members, no
+collective on the data path, "weak" scaling, `value` = steps of all ranks per second).
 
 One JSON line on stdout (rank 0), with two extra objects:
   roofline      the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs / mean launch time measured
@@ -159,18 +162,35 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from datetime import timedelta
+
+        # Test hooks (single-GPU boxes): AURORA_BENCH_SAME_GPU=1 puts every rank on cuda:0 and
+        # AURORA_BENCH_BACKEND=gloo replaces RCCL (which needs one GPU per rank) by host-staged gloo.
+        if os.environ.get("AURORA_BENCH_SAME_GPU"):
+            local_rank = 0
+        backend = os.environ.get("AURORA_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, timeout=timedelta(seconds=300), **kw)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
     from aurora_amd.engine import lib
 
-    log("building model")
-    model = build_model(device)
+    mode = os.environ.get("AURORA_BENCH_MODE", "bands") if distributed else "single"
+    assert mode in ("bands", "replicas", "single"), mode
+    log(f"building model (mode {mode})")
+    model = build_model(device)  # same seed on every rank: identical weights
     log("model on device; building batch")
-    batch = synthetic_batch(model.config, 721, 1440, 1 + rank, device)
+    if mode == "bands":
+        # one forecast, identical inputs everywhere; each rank keeps its latitude band resident
+        model.configure_sharding(rank, world, gather_output=False)
+        full = synthetic_batch(model.config, 721, 1440, 1, device)
+        batch = model.engine().local_band(full.crop(model.patch_size))
+        del full
+    else:
+        batch = synthetic_batch(model.config, 721, 1440, 1 + rank, device)
     log("batch on device")
 
     def barrier():
@@ -195,13 +215,13 @@ def main() -> None:
     assert torch.isfinite(pred.surf_vars["2t"]).all()
 
     if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * args.steps / elapsed
+        value = (1 if mode == "bands" else world) * args.steps / elapsed
         g = prof.get("linear_bf16", {"launches": 0, "ms": 0.0, "work": 0.0})
         a = prof.get("window_attention_bf16", {"launches": 0, "ms": 0.0, "work": 0.0})
         gemm_tf = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else 0.0
@@ -214,10 +234,15 @@ def main() -> None:
             "metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13",
             "value": value, "unit": "forecast-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong" if mode == "bands" else "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
             "config": {"workload": "AuroraPretrained(autocast=True) 1.3B, 0.25deg ERA5 721x1440, 13 levels, "
                                    "T=2, batch 1 per GPU, one forward step (BASELINE.json configs[1])",
-                       "parallelism": f"replica x{world} (independent forecasts, no data-path collective)"},
+                       "parallelism": {"single": "1 GPU",
+                                       "bands": f"one forecast over {world} latitude bands, RCCL halo exchange "
+                                                "(3 rows per shifted block and side), state kept distributed",
+                                       "replicas": f"replica x{world} (independent forecasts, no data-path "
+                                                   "collective)"}[mode]},
             "roofline": {
                 "kernel": "linear_kernel<bf16> (MFMA GEMM, all backbone linears)", "bound": "mfma",
                 "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

@@ -136,3 +136,52 @@ def test_gather_rows_and_band_output_limit():
     out = lib.gather_rows(src, idx, torch.empty(5, 64, device="cuda"))
     torch.cuda.synchronize()
     assert torch.equal(out, src[idx.long()])
+
+
+def _proc(rank, world, port, ret):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    model, batch = make("base_pad", False, 192, 96)
+    with torch.inference_mode():
+        ref = model.forward(batch) if rank == 0 else None
+        model.configure_sharding(rank, world, gather_output=True)
+        full = model.forward(batch)                       # every rank gets the whole prediction
+        model.configure_sharding(rank, world, gather_output=False)
+        preds = list(aurora_amd.rollout(model, batch, steps=2))  # state stays distributed
+    torch.cuda.synchronize()
+    assert isinstance(preds[1], BandBatch) and preds[1].metadata.rollout_step == 2
+    if rank == 0:
+        err = max(helpers.rel_err(full.atmos_vars[k].cpu(), v.cpu()) for k, v in ref.atmos_vars.items())
+        err = max(err, max(helpers.rel_err(full.surf_vars[k].cpu(), v.cpu()) for k, v in ref.surf_vars.items()))
+        h0, h1 = preds[0].band
+        P = model.patch_size
+        err_band = max(helpers.rel_err(preds[0].atmos_vars[k].cpu(), v[..., h0 * P:h1 * P, :].cpu())
+                       for k, v in ref.atmos_vars.items())
+        ret.put((err, err_band, tuple(full.surf_vars["2t"].shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multiprocess_sharding_on_one_gpu(world):
+    """The production code path (configure_sharding + forward / rollout, torch.distributed P2P halo
+    exchange, broadcast gather) with real processes; transport = gloo with host staging because
+    several ranks share this box's single GPU (RCCL needs one GPU per rank)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_proc, args=(r, world, 29700 + world, ret)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(timeout=300)
+        assert p_.exitcode == 0
+    err, err_band, shape = ret.get(timeout=10)
+    assert shape == (1, 1, 192, 96)
+    assert err < 2e-6 and err_band < 2e-6
