@@ -60,6 +60,20 @@ class Metadata:
             )
 
 
+def derive_metadata(md: Metadata, **changes) -> Metadata:
+    """`dataclasses.replace` for metadata whose coordinates were validated already.
+
+    Validation reads the coordinates on the host; for device-resident batches that is a
+    device->host synchronisation per check.  Moving, casting or slicing valid coordinates keeps them
+    valid, so the per-step paths (and hipGraph capture, where such a sync is illegal) derive new
+    metadata without re-validating.
+    """
+    new = object.__new__(Metadata)
+    for f in dataclasses.fields(Metadata):
+        object.__setattr__(new, f.name, changes.get(f.name, getattr(md, f.name)))
+    return new
+
+
 @dataclasses.dataclass
 class Batch:
     """A batch of data.
@@ -117,12 +131,12 @@ class Batch:
                 f"There can at most be one latitude too many, but there are {extra} too many."
             )
         cut = lambda d: {k: v[..., :-1, :] for k, v in d.items()}  # noqa: E731
-        md = dataclasses.replace(self.metadata, lat=self.metadata.lat[:-1])
+        md = derive_metadata(self.metadata, lat=self.metadata.lat[:-1])
         return dataclasses.replace(self, surf_vars=cut(self.surf_vars), static_vars=cut(self.static_vars),
                                    atmos_vars=cut(self.atmos_vars), metadata=md)
 
     def _fmap(self, f: Callable[[torch.Tensor], torch.Tensor]) -> "Batch":
-        md = dataclasses.replace(self.metadata, lat=f(self.metadata.lat), lon=f(self.metadata.lon))
+        md = derive_metadata(self.metadata, lat=f(self.metadata.lat), lon=f(self.metadata.lon))
         return dataclasses.replace(
             self,
             surf_vars={k: f(v) for k, v in self.surf_vars.items()},

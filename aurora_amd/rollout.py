@@ -12,12 +12,19 @@ from aurora_amd.batch import Batch
 __all__ = ["rollout"]
 
 
-def rollout(model, batch: Batch, steps: int) -> Generator[Batch, None, None]:
+def rollout(model, batch: Batch, steps: int, graph: bool = False) -> Generator[Batch, None, None]:
     """Yield `steps` successive predictions, feeding each one back as the newest history state.
 
     The batch is brought to the model's dtype/device once; every prediction stays on the
     device (callers typically `.to("cpu")` what they keep, docs/usage.md:136-141 upstream).
+
+    `graph=True` (not in the reference) captures the step as a hipGraph after a warm-up step and
+    replays it: one host call per step instead of ~750 kernel launches; the history is shifted inside
+    the graph.  A new graph is captured whenever the LoRA weight set / clamping phase of the step changes.
     """
+    if graph:
+        yield from _rollout_graphed(model, batch, steps)
+        return
     batch = model.batch_transform_hook(batch)
     p = next(model.parameters())
     batch = batch.type(p.dtype).crop(model.patch_size).to(p.device)
@@ -41,3 +48,15 @@ def rollout(model, batch: Batch, steps: int) -> Generator[Batch, None, None]:
                 for k, v in pred.atmos_vars.items()
             },
         )
+
+
+def _rollout_graphed(model, batch: Batch, steps: int) -> Generator[Batch, None, None]:
+    engine = model.engine()
+    stepper = None
+    state = batch
+    for _ in range(steps):
+        if stepper is None or engine.step_signature(stepper.state.metadata.rollout_step) != stepper.signature:
+            if stepper is not None:
+                state = stepper.state   # continue from the captured state with a new weight set
+            stepper = engine.capture(state)
+        yield stepper.advance()

@@ -149,3 +149,23 @@ def test_inputs_are_not_mutated_and_outputs_are_fresh():
         assert torch.equal(v, before[k])
     assert torch.equal(p1.surf_vars["2t"], keep)          # a second step does not clobber the first
     assert torch.equal(p1.surf_vars["2t"], p2.surf_vars["2t"])  # deterministic
+
+
+@pytest.mark.parametrize("name,autocast", [("base_pad", False), ("base_pad", True), ("lora_all", False),
+                                           ("air_pollution", False)])
+def test_graph_captured_rollout_equals_eager(name, autocast):
+    """BASELINE config 3 in miniature: roll-out with the step replayed from a hipGraph."""
+    case, model, batch = build(name, autocast=autocast)
+    steps = max(case["steps"], 3)
+    with torch.inference_mode():
+        eager = list(rollout(model, batch, steps=steps))
+        graphed = list(rollout(model, batch, steps=steps, graph=True))
+    torch.cuda.synchronize()
+    for e, g in zip(eager, graphed):
+        assert g.metadata.time == e.metadata.time and g.metadata.rollout_step == e.metadata.rollout_step
+        for k in e.surf_vars:
+            assert torch.equal(g.surf_vars[k], e.surf_vars[k]), k
+        for k in e.atmos_vars:
+            assert torch.equal(g.atmos_vars[k], e.atmos_vars[k]), k
+    # predictions handed out earlier are not overwritten by later replays
+    assert not torch.equal(graphed[0].surf_vars["2t"], graphed[1].surf_vars["2t"])
