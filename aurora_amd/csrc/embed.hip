@@ -37,6 +37,11 @@ __device__ __forceinline__ float patch_transform(float z, const PatchVar& d) {
     const float f1 = (logf(fmaxf(z, eps)) - log_eps) / (-log_eps);
     return d.tw0 * f0 + d.tw1 * f1 + d.tb;
   }
+  // ocean-wave variant (reference aurora.py:892-912): missing values are NaN in the input
+  if (d.transform == 3) return isnan(z) ? 0.f : 1.f;                       // density channel
+  if (d.transform == 4) return isnan(z) ? 0.f : z;                         // value, nan_to_num(0)
+  if (d.transform == 5) { const float r = sinf(z * 0.017453292519943295f); return isnan(r) ? 0.f : r; }
+  if (d.transform == 6) { const float r = cosf(z * 0.017453292519943295f); return isnan(r) ? 0.f : r; }
   return z;
 }
 
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AsmArgs p) {
 struct UnpatchVar {
   float* dst; const float* loc; const float* scale; int32_t clamp_min0, col0, lvl_stride, mod_col0;
   const float* prev; int64_t prev_sb, prev_sc, prev_sh; const float* inv_scale; uint32_t clamp_max1_levels;
+  int32_t angle_col0, dens_col0; const float* mask; int64_t mask_sh; float mask_thresh;
 };
 struct UnpatchArgs {
   UnpatchVar v[MAX_VARS];
@@ -205,11 +211,23 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const UnpatchArgs p) {
   const float* prev = has_mod ? d.prev + b * d.prev_sb + c * d.prev_sc + hh * d.prev_sh + ww : nullptr;
   const float inv = has_mod ? d.inv_scale[c] : 0.f;
   const bool cap1 = (d.clamp_max1_levels >> c) & 1u;
+  const float* cosp = d.angle_col0 >= 0 ? row + d.angle_col0 : nullptr;   // wave: col0 = sin head, this = cos head
+  const float* dens = d.dens_col0 >= 0 ? row + d.dens_col0 : nullptr;     // wave: density head
+  const float* maskp = dens ? d.mask + hh * d.mask_sh + ww : nullptr;     // raw water-body mask plane
   for (int j = 0; j < p.P; ++j) {
     float z = src[j];
     if (has_mod) z = z + (1.0f + mod[j]) * ((prev[j] - loc) * inv);
     if (cap1) z = fminf(z, 1.0f);
     if (d.clamp_min0) z = fmaxf(z, 0.f);
+    if (cosp) {  // direction from its sin / cos heads: rad2deg(atan2(sin, cos)) mod 360 in [0, 360)
+      z = atan2f(z, cosp[j]) * 57.29577951308232f;
+      z = fmodf(z, 360.0f);
+      if (z < 0.f) z += 360.0f;
+    }
+    if (dens) {  // present only over water AND where sigmoid(density) >= 0.5 (aurora.py:924-930)
+      const bool water = maskp[j] > d.mask_thresh;
+      z = (water && !(dens[j] < 0.f)) ? z : __int_as_float(0x7fc00000);
+    }
     dst[j] = z * sc + loc;
   }
 }
@@ -299,7 +317,8 @@ extern "C" int aurora_hip_unpatchify(const float* y, int64_t ldy, const aurora_u
   for (int v = 0; v < n_vars; ++v)
     p.v[v] = UnpatchVar{desc[v].dst, desc[v].loc, desc[v].scale, desc[v].clamp_min0, desc[v].col0,
                         desc[v].lvl_stride, desc[v].mod_col0, desc[v].prev, desc[v].prev_sb, desc[v].prev_sc,
-                        desc[v].prev_sh, desc[v].inv_scale, desc[v].clamp_max1_levels};
+                        desc[v].prev_sh, desc[v].inv_scale, desc[v].clamp_max1_levels, desc[v].angle_col0,
+                        desc[v].dens_col0, desc[v].mask, desc[v].mask_sh, desc[v].mask_thresh};
   p.y = y; p.ldy = ldy; p.n_vars = n_vars; p.B = B; p.n_lvl = n_lvl; p.Hp = Hp; p.Wp = Wp; p.P = P;
   const int64_t items = (int64_t)n_vars * B * n_lvl * Hp * P * Wp;
   AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "unpatchify: bad problem size");

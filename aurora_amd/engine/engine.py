@@ -81,8 +81,6 @@ class Engine:
                 f"aurora_amd computes in fp32 (or bf16 backbone with autocast=True); parameters "
                 f"are {p.dtype}. Keep the model in float32."
             )
-        if model.variant == "wave":
-            raise NotImplementedError("AuroraWave hooks are not implemented in the HIP engine yet.")
         self.device = p.device
         self.bb_dtype = BF16 if model.autocast else F32
         cfg = self.cfg
@@ -432,7 +430,8 @@ class Engine:
         model, cfg = self.model, self.cfg
         if self.is_stale():
             raise RuntimeError("model parameters changed after packing: call model._engine = None first")
-        batch = model.batch_transform_hook(batch)
+        if not self._capturing:  # (a captured step runs on a batch the hook has already seen)
+            batch = model.batch_transform_hook(batch)
         P, D = cfg.patch_size, cfg.embed_dim
         sh = self.shard if (self.shard is not None and self.shard.world > 1) else None
         band = None
@@ -597,6 +596,23 @@ class Engine:
             tw0, tw1, tb = comb
         return lib.PatchVar(t.data_ptr(), sb, st, sc, sh, sw, loc.data_ptr(), inv.data_ptr(), transform, tw0, tw1, tb)
 
+    def _wave_channels(self, names: tuple) -> list:
+        """Model input channels of the ocean-wave variant for the surface variables `names`:
+        [(channel name, source variable, patchify transform code)], in the order the reference's
+        `_pre_encoder_hook` leaves the dictionary (kept variables, then the appended channels)."""
+        model = self.model
+        kept, appended = [], []
+        for k in names:
+            dens = k in model.density_channel_surf_vars and f"{k}_density" not in names
+            ang = k in model.angle_surf_vars and not (f"{k}_sin" in names and f"{k}_cos" in names)
+            if not ang:
+                kept.append((k, k, 4 if dens else 0))
+            if dens:
+                appended.append((f"{k}_density", k, 3))
+            if ang:
+                appended += [(f"{k}_sin", k, 5), (f"{k}_cos", k, 6)]
+        return kept + appended
+
     def _combiner(self, kind: str, name: str):
         """(w0, w1, b) of the air-pollution Linear(2, 1) feature combiner, read to the host once."""
         key = ("combiner", kind, name)
@@ -626,8 +642,14 @@ class Engine:
         atmos = {k: f32c(v) for k, v in batch.atmos_vars.items()}
         keep += list(surf.values()) + list(static.values()) + list(atmos.values())
 
-        surf_names = tuple(surf) + tuple(static)
-        descs = [self._var_desc(v, "surf", k, levels, *transform_of("surf", k)) for k, v in surf.items()]
+        if model.variant == "wave":
+            # density channels and sin/cos of directions (aurora.py:892-912) as per-channel transforms
+            chans = self._wave_channels(tuple(surf))
+            surf_names = tuple(n for n, _, _ in chans) + tuple(static)
+            descs = [self._var_desc(surf[src], "surf", src, levels, code) for _, src, code in chans]
+        else:
+            surf_names = tuple(surf) + tuple(static)
+            descs = [self._var_desc(v, "surf", k, levels, *transform_of("surf", k)) for k, v in surf.items()]
         descs += [self._var_desc(v, "surf", k, levels) for k, v in static.items()]
         tbufs = self._time_inputs(batch.metadata.time, B)
         dyn_t = []
@@ -910,7 +932,15 @@ class Engine:
         diff = type(model)._predict_difference_history_dim_lookup if model.variant == "air_pollution" else {}
 
         surf_in, atmos_in = tuple(batch.surf_vars), tuple(batch.atmos_vars)
-        surf_heads = surf_in + tuple(f"{n}_mod" for n in surf_in if n in cfg.modulation_heads)
+        wave = model.variant == "wave"
+        if wave:
+            chans = self._wave_channels(surf_in)
+            surf_heads = tuple(n for n, _, _ in chans)
+            # output order of the reference's post hook: kept variables, then the directions
+            kept = tuple(n for n, s_, _ in chans if n == s_)
+            surf_in = kept + tuple(a for a in model.angle_surf_vars if f"{a}_sin" in surf_heads and a not in kept)
+        else:
+            surf_heads = surf_in + tuple(f"{n}_mod" for n in surf_in if n in cfg.modulation_heads)
         atmos_heads = atmos_in + tuple(f"{n}_mod" for n in atmos_in if n in cfg.modulation_heads)
         P2 = P * P
 
@@ -925,9 +955,19 @@ class Engine:
         descs = []
         for i, n in enumerate(surf_in):
             loc, sc, _ = self._stats("surf", n, levels)
-            d = lib.UnpatchVar(out_s[i].data_ptr(), loc.data_ptr(), sc.data_ptr(),
-                               int(clamp_now and n in cfg.positive_surf_vars), surf_heads.index(n) * P2)
+            first = f"{n}_sin" if (wave and n not in surf_heads) else n
+            d = lib.unpatch_var(out_s[i].data_ptr(), loc.data_ptr(), sc.data_ptr(),
+                                int(clamp_now and n in cfg.positive_surf_vars), surf_heads.index(first) * P2)
             self._diff_fields(d, n, diff, surf_heads, P2, 0, batch.surf_vars, levels, False)
+            if wave:
+                if first != n:
+                    d.angle_col0 = surf_heads.index(f"{n}_cos") * P2
+                if f"{n}_density" in surf_heads:
+                    wmb = batch.static_vars["wmb"]
+                    assert wmb.stride(-1) == 1
+                    d.dens_col0 = surf_heads.index(f"{n}_density") * P2
+                    d.mask, d.mask_sh = wmb.data_ptr(), wmb.stride(0)
+                    d.mask_thresh = normalisation.surf_affine("wmb", model.surf_stats)[0]  # normalised > 0
             descs.append(d)
         for i in range(0, len(descs), 32):
             lib.unpatchify(y_s, descs[i:i + 32], B, 1, Hp, Wp, P)
@@ -961,8 +1001,8 @@ class Engine:
                     continue  # consumed by its base variable
                 i = atmos_in.index(n)
                 loc, sc, _ = self._stats("atmos", n, levels)
-                d = lib.UnpatchVar(out_a[i].data_ptr(), loc.data_ptr(), sc.data_ptr(),
-                                   int(clamp_now and n in cfg.positive_atmos_vars), names.index(n) * P2)
+                d = lib.unpatch_var(out_a[i].data_ptr(), loc.data_ptr(), sc.data_ptr(),
+                                    int(clamp_now and n in cfg.positive_atmos_vars), names.index(n) * P2)
                 d.lvl_stride = lvl_stride
                 self._diff_fields(d, n, diff, names, P2, lvl_stride, batch.atmos_vars, levels, True)
                 if model.variant == "air_pollution" and cfg.use_lora and n == "so2":

@@ -33,7 +33,16 @@ class UnpatchVar(ctypes.Structure):
     _fields_ = [("dst", c_void_p), ("loc", c_void_p), ("scale", c_void_p),
                 ("clamp_min0", c_int32), ("col0", c_int32), ("lvl_stride", c_int32), ("mod_col0", c_int32),
                 ("prev", c_void_p), ("prev_sb", c_int64), ("prev_sc", c_int64), ("prev_sh", c_int64),
-                ("inv_scale", c_void_p), ("clamp_max1_levels", ctypes.c_uint32)]
+                ("inv_scale", c_void_p), ("clamp_max1_levels", ctypes.c_uint32),
+                ("angle_col0", c_int32), ("dens_col0", c_int32), ("mask", c_void_p), ("mask_sh", c_int64),
+                ("mask_thresh", c_float)]
+
+
+def unpatch_var(dst: int, loc: int, scale: int, clamp_min0: int, col0: int) -> UnpatchVar:
+    """An `aurora_unpatch_var` with every optional feature switched off."""
+    d = UnpatchVar(dst, loc, scale, clamp_min0, col0)
+    d.mod_col0 = d.angle_col0 = d.dens_col0 = -1
+    return d
 
 
 _SIGNATURES = {

@@ -59,4 +59,12 @@ def _rollout_graphed(model, batch: Batch, steps: int) -> Generator[Batch, None, 
             if stepper is not None:
                 state = stepper.state   # continue from the captured state with a new weight set
             stepper = engine.capture(state)
-        yield stepper.advance()
+        pred = stepper.advance()
+        yield pred
+        if tuple(pred.surf_vars) != tuple(stepper.state.surf_vars):
+            # The ocean-wave variant returns the directions after the other variables, and the eager
+            # roll-out (like the reference's) carries on in the prediction's order, which fixes the
+            # summation order of the patch embedding.  Follow it: reorder and capture anew.
+            st = stepper.state
+            state = dataclasses.replace(st, surf_vars={k: st.surf_vars[k] for k in pred.surf_vars})
+            stepper = None

@@ -114,7 +114,9 @@ int aurora_hip_split_ln(const void* y, const float* ln_w, const float* ln_b, voi
  * `src`, `loc`, `inv_scale` members are device pointers.  Strides are in elements and may be
  * 0 (static variables broadcast over batch/history/level; constant planes).
  * transform codes: 0 none, 1 clamp(min=0) (aurora.py:301-317), 2 clamp + air-pollution
- * feature combiner (aurora.py:733-742) with Linear(2,1) weights tw0, tw1 and bias tb.
+ * feature combiner (aurora.py:733-742) with Linear(2,1) weights tw0, tw1 and bias tb;
+ * ocean-wave channels (aurora.py:892-912, NaN = missing): 3 density = !isnan, 4 value with
+ * NaN -> 0, 5 sin(deg2rad(x)) and 6 cos(deg2rad(x)), both with NaN -> 0.
  */
 typedef struct aurora_patch_var {
   const float* src;       /* device: first element of the variable                           */
@@ -163,7 +165,10 @@ int aurora_hip_assemble_tokens(const float* surf, const float* agg, const float*
  *                                                 y_mod at mod_col0 (>= 0), prev the raw previous
  *                                                 state of the same variable
  *   then z = min(z, 1) on the levels in clamp_max1_levels (bit c; SO2 fix aurora.py:781-794)
- *   then g = clamp(min=0) if clamp_min0 (aurora.py:368-388).
+ *   then g = clamp(min=0) if clamp_min0 (aurora.py:368-388);
+ *   ocean-wave post hook (aurora.py:914-932): angle_col0 >= 0 makes col0 / angle_col0 the sin / cos
+ *   heads of a direction, z = rad2deg(atan2(sin, cos)) mod 360; dens_col0 >= 0 keeps z only where
+ *   mask[h][w] > mask_thresh (water) and the density head is >= 0 (sigmoid >= 0.5), else NaN.
  * `desc`: HOST array of n_vars (<= 32) descriptors with device pointers inside.
  */
 typedef struct aurora_unpatch_var {
@@ -178,6 +183,11 @@ typedef struct aurora_unpatch_var {
   int64_t prev_sb, prev_sc, prev_sh;
   const float* inv_scale; /* device [n_lvl] 1/scale (only read when mod_col0 >= 0)            */
   uint32_t clamp_max1_levels;
+  int32_t angle_col0;     /* -1: not a direction                                              */
+  int32_t dens_col0;      /* -1: no density channel                                           */
+  const float* mask;      /* device, raw water-body mask plane (H, W), row stride mask_sh     */
+  int64_t mask_sh;
+  float mask_thresh;      /* raw-units threshold equivalent to "normalised value > 0"         */
 } aurora_unpatch_var;
 
 int aurora_hip_unpatchify(const float* y, int64_t ldy, const aurora_unpatch_var* desc, int n_vars,

@@ -564,6 +564,63 @@ def _pollution_pre(sd, kind: str, name: str, z: Tensor) -> Tensor:
     return linear(sd, f"{kind}_feature_combiner.{name}", feats)[..., 0]
 
 
+WAVE_DENSITY_VARS = ("swh", "mwd", "mwp", "pp1d", "shww", "mdww", "mpww", "shts", "mdts", "mpts", "swh1", "mwd1",
+                     "mwp1", "swh2", "mwd2", "mwp2", "wind", "10u_wave", "10v_wave")   # aurora.py:819-822
+WAVE_ANGLE_VARS = ("mwd", "mdww", "mdts", "mwd1", "mwd2")                              # aurora.py:823
+
+
+def wave_batch_transform(surf: Mapping[str, Tensor], rollout_step: int) -> dict:
+    """aurora.py:854-890: wind speed/direction -> components; absent wave systems -> NaN (raw data only)."""
+    surf = dict(surf)
+    if "dwi" in surf and "wind" in surf:
+        surf["10u_wave"] = -surf["wind"] * torch.sin(torch.deg2rad(surf["dwi"]))
+        surf["10v_wave"] = -surf["wind"] * torch.cos(torch.deg2rad(surf["dwi"]))
+        del surf["dwi"]
+    if rollout_step == 0:
+        for height, others in (("swh", ("mwd", "mwp", "pp1d")), ("shww", ("mdww", "mpww")),
+                               ("shts", ("mdts", "mdts")), ("swh1", ("mwd1", "mwp1")), ("swh2", ("mwd2", "mwp2"))):
+            gone = surf[height] < 1e-4
+            if gone.sum() > 0:
+                for name in (height,) + others:
+                    x = surf[name].clone()
+                    x[gone] = float("nan")
+                    surf[name] = x
+    return surf
+
+
+def _wave_pre(surf: dict) -> dict:
+    """aurora.py:892-912 on the normalised variables (the dictionary is extended while iterating a copy
+    of its keys, so new channels go to the end in creation order)."""
+    surf = dict(surf)
+    for name in list(surf):
+        x = surf[name]
+        if name in WAVE_DENSITY_VARS and f"{name}_density" not in surf:
+            surf[f"{name}_density"] = (~torch.isnan(x)).to(x.dtype)
+            surf[name] = x.nan_to_num(0)
+        if name in WAVE_ANGLE_VARS and not (f"{name}_sin" in surf and f"{name}_cos" in surf):
+            surf[f"{name}_sin"] = torch.sin(torch.deg2rad(x)).nan_to_num(0)
+            surf[f"{name}_cos"] = torch.cos(torch.deg2rad(x)).nan_to_num(0)
+            del surf[name]
+    return surf
+
+
+def _wave_post(pred: dict, wmb: Tensor) -> dict:
+    """aurora.py:914-941: angles back from sin/cos; values NaN where the density head says 'absent'
+    or outside water bodies."""
+    pred = dict(pred)
+    water = wmb > 0
+    for name in WAVE_ANGLE_VARS:
+        if f"{name}_sin" in pred and f"{name}_cos" in pred:
+            pred[name] = torch.rad2deg(torch.atan2(pred.pop(f"{name}_sin"), pred.pop(f"{name}_cos"))) % 360
+    for name in WAVE_DENSITY_VARS:
+        if name in pred:
+            density = torch.sigmoid(pred.pop(f"{name}_density")) * water
+            data = pred[name] * water
+            data[density < 0.5] = float("nan")
+            pred[name] = data
+    return pred
+
+
 def forward(sd: Mapping[str, Tensor], cfg, surf: Mapping[str, Tensor], static: Mapping[str, Tensor],
             atmos: Mapping[str, Tensor], lat: Tensor, lon: Tensor, times: Sequence[datetime],
             levels: Sequence[float], rollout_step: int, locations: Mapping[str, float],
@@ -574,13 +631,16 @@ def forward(sd: Mapping[str, Tensor], cfg, surf: Mapping[str, Tensor], static: M
     surf: name -> (B, T, H, W); static: name -> (H, W); atmos: name -> (B, T, C, H, W).
     Returns (surf_pred {name: (B, 1, H', W)}, atmos_pred {name: (B, 1, C, H', W)}, lat')
     in physical units, where H' drops the last latitude row if H % patch == 1
-    (batch.py:142-168).  `variant` is "base" or "air_pollution" (hooks aurora.py:726-796).
+    (batch.py:142-168).  `variant` is "base", "air_pollution" (hooks aurora.py:726-796) or "wave"
+    (hooks aurora.py:854-941).
     """
     dtype = next(iter(sd.values())).dtype
     P = cfg.patch_size
     cast = lambda d: {k: v.to(dtype) for k, v in d.items()}  # noqa: E731
     surf, static, atmos = cast(surf), cast(static), cast(atmos)
     lat, lon = lat.to(dtype), lon.to(dtype)
+    if variant == "wave":
+        surf = wave_batch_transform(surf, rollout_step)
 
     surf = {k: _norm_surf(v, k, surf_stats, locations, scales) for k, v in surf.items()}
     static = {k: _norm_surf(v, k, surf_stats, locations, scales) for k, v in static.items()}
@@ -612,6 +672,10 @@ def forward(sd: Mapping[str, Tensor], cfg, surf: Mapping[str, Tensor], static: M
         enc_atmos = {k: _pollution_pre(sd, "atmos", k, v) if k in cfg.positive_atmos_vars else v
                      for k, v in enc_atmos.items()}
 
+    if variant == "wave":
+        # (the reference mutates the batch the decoder sees, so the heads follow the expanded names)
+        surf = enc_surf = _wave_pre(enc_surf)
+
     x = encoder_forward(sd, cfg, enc_surf, static_bt, enc_atmos, lat, lon, times, levels)
     ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()
     with ctx:
@@ -635,6 +699,9 @@ def forward(sd: Mapping[str, Tensor], cfg, surf: Mapping[str, Tensor], static: M
                      else atmos_pred["so2"][..., i, :, :] for i, lv in enumerate(levels)]
             atmos_pred["so2"] = torch.stack(parts, dim=-3)
 
+    if variant == "wave":
+        surf_pred = _wave_post(surf_pred, static["wmb"])
+
     new_step = rollout_step + 1
     if new_step >= 1 if cfg.clamp_at_first_step else new_step > 1:
         surf_pred = {k: v.clamp(min=0) if k in cfg.positive_surf_vars else v
@@ -655,6 +722,8 @@ def rollout(sd, cfg, surf, static, atmos, lat, lon, times, levels, steps: int, l
     surf = {k: v.to(dtype) for k, v in surf.items()}
     atmos = {k: v.to(dtype) for k, v in atmos.items()}
     static = {k: v.to(dtype) for k, v in static.items()}
+    if kw.get("variant") == "wave":
+        surf = wave_batch_transform(surf, 0)
     H = next(iter(surf.values())).shape[-2]
     if H % P == 1:
         cut = lambda d: {k: v[..., :-1, :] for k, v in d.items()}  # noqa: E731

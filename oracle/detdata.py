@@ -120,3 +120,32 @@ def det_inputs(surf_vars: Sequence[str], static_vars: Sequence[str], atmos_vars:
     # timezone-aware, so that `.timestamp()` does not depend on the host's TZ setting
     times = tuple(datetime(2020, 6, 1 + b, 12, 0, tzinfo=timezone.utc) for b in range(B))
     return surf, static, atmos, lat, lon, times
+
+
+# Raw input variables of the ocean-wave variant: wind as speed + direction (`dwi`), which the model's
+# batch transform splits into 10u_wave / 10v_wave (aurora.py:863-871 upstream).
+WAVE_RAW_SURF = ("2t", "10u", "10v", "msl", "swh", "mwd", "mwp", "pp1d", "shww", "mdww", "mpww", "shts", "mdts",
+                 "mpts", "swh1", "mwd1", "mwp1", "swh2", "mwd2", "mwp2", "wind", "dwi")
+_WAVE_HEIGHTS = ("swh", "shww", "shts", "swh1", "swh2")
+_WAVE_ANGLES = ("mwd", "mdww", "mdts", "mwd1", "mwd2", "dwi")
+
+
+def det_wave_inputs(static_vars: Sequence[str], atmos_vars: Sequence[str], B: int, T: int, H: int, W: int,
+                    levels: Sequence[float], locations: Mapping[str, float], scales: Mapping[str, float],
+                    seed: int = 1):
+    """`det_inputs` for AuroraWave: strictly positive wave parameters, directions in [0, 360) degrees,
+    and about a fifth of every wave system's heights exactly zero (absent system -> NaN marking)."""
+    loc = dict(locations, dwi=0.0)
+    sc = dict(scales, dwi=1.0)
+    surf, static, atmos, lat, lon, times = det_inputs(WAVE_RAW_SURF, static_vars, atmos_vars, B, T, H, W, levels,
+                                                      loc, sc, seed)
+    for v in WAVE_RAW_SURF[4:]:
+        u = det_uniform(f"in.surf.{v}", (B, T, H, W), seed)
+        if v in _WAVE_ANGLES:
+            x = (u + 1.0) * 180.0
+        else:
+            x = (u + 1.1) * sc[v]
+            if v in _WAVE_HEIGHTS:
+                x = np.where(det_uniform(f"in.absent.{v}", (B, T, H, W), seed) < -0.6, 0.0, x)
+        surf[v] = torch.from_numpy(x)
+    return surf, static, atmos, lat, lon, times

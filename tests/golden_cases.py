@@ -54,4 +54,10 @@ CASES = {
         cls="AuroraAirPollution",
         kwargs=dict(**_TINY), H=25, W=48, B=1, T=2, levels=(50, 500, 850, 1000), steps=2,
     ),
+    # Ocean-wave variant: wind speed/direction split, NaN marking of absent wave systems, density
+    # channels, sin/cos of directions and their inverse, water-body masking; LoRA from the second step.
+    "wave": dict(
+        cls="AuroraWave",
+        kwargs=dict(**_TINY), H=17, W=32, B=1, T=2, levels=(100, 250, 500, 850), steps=2,
+    ),
 }

@@ -29,6 +29,9 @@ def case_state_dict(model, dtype=torch.float64):
 
 
 def case_inputs(case, cfg):
+    if case["cls"] == "AuroraWave":
+        return detdata.det_wave_inputs(cfg.static_vars, cfg.atmos_vars, case["B"], case["T"], case["H"], case["W"],
+                                       case["levels"], normalisation.locations, normalisation.scales)
     return detdata.det_inputs(
         cfg.surf_vars, cfg.static_vars, cfg.atmos_vars, case["B"], case["T"], case["H"], case["W"],
         case["levels"], normalisation.locations, normalisation.scales,
@@ -39,6 +42,15 @@ def case_inputs(case, cfg):
 def load_golden(name: str) -> dict[str, np.ndarray]:
     with np.load(GOLD / f"{name}.npz") as z:
         return {k: z[k] for k in z.files}
+
+
+def nan_agreement(a: torch.Tensor, b: torch.Tensor):
+    """(a', b', fraction of points where exactly one of a, b is NaN): the points where both are
+    finite, for value comparison, and how often the NaN masks disagree (ocean-wave outputs carry NaN
+    for absent wave systems; a density logit within rounding of 0 may legitimately flip)."""
+    na, nb = torch.isnan(a), torch.isnan(b)
+    both = ~na & ~nb
+    return a[both], b[both], (na ^ nb).double().mean().item()
 
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:

@@ -38,8 +38,9 @@ def test_ctypes_structs_match_header_layout():
     assert ctypes.sizeof(shim.PatchVar) == 80
     assert [f[0] for f in shim.UnpatchVar._fields_] == [
         "dst", "loc", "scale", "clamp_min0", "col0", "lvl_stride", "mod_col0", "prev", "prev_sb",
-        "prev_sc", "prev_sh", "inv_scale", "clamp_max1_levels"]
-    assert ctypes.sizeof(shim.UnpatchVar) == 88
+        "prev_sc", "prev_sh", "inv_scale", "clamp_max1_levels", "angle_col0", "dens_col0", "mask", "mask_sh",
+        "mask_thresh"]
+    assert ctypes.sizeof(shim.UnpatchVar) == 120
 
 
 def test_argument_errors_surface_without_a_gpu(built):

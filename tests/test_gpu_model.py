@@ -47,9 +47,13 @@ def test_fp32_engine_matches_reference_golden(name):
                 for k, v in d.items():
                     ref = torch.from_numpy(gold[f"s{s}.{kind}.{k}"])
                     assert v.shape == ref.shape and v.is_cuda
-                    worst[f"s{s}.{kind}.{k}"] = (helpers.mean_rel_err(v.cpu(), ref), helpers.rel_err(v.cpu(), ref))
+                    v, ref, flipped = helpers.nan_agreement(v.cpu(), ref)
+                    assert flipped <= 2e-3, (k, flipped)   # (only the wave variant produces NaN at all)
+                    worst[f"s{s}.{kind}.{k}"] = (helpers.mean_rel_err(v, ref), helpers.rel_err(v, ref))
             for k, v in pred.static_vars.items():
                 assert torch.allclose(v.cpu(), batch.static_vars[k][: v.shape[0]])
+            if name == "wave":
+                assert "dwi" not in pred.surf_vars and torch.isnan(pred.surf_vars["swh"]).any()
     print(name, "worst mean-rel", max(w[0] for w in worst.values()), "worst max-rel", max(w[1] for w in worst.values()))
     assert len(worst) == len(gold)
     bad = {k: w for k, w in worst.items() if w[0] > 1e-4 or w[1] > 1e-3}
@@ -152,7 +156,7 @@ def test_inputs_are_not_mutated_and_outputs_are_fresh():
 
 
 @pytest.mark.parametrize("name,autocast", [("base_pad", False), ("base_pad", True), ("lora_all", False),
-                                           ("air_pollution", False)])
+                                           ("air_pollution", False), ("wave", False)])
 def test_graph_captured_rollout_equals_eager(name, autocast):
     """BASELINE config 3 in miniature: roll-out with the step replayed from a hipGraph."""
     case, model, batch = build(name, autocast=autocast)
@@ -164,7 +168,7 @@ def test_graph_captured_rollout_equals_eager(name, autocast):
     for e, g in zip(eager, graphed):
         assert g.metadata.time == e.metadata.time and g.metadata.rollout_step == e.metadata.rollout_step
         for k in e.surf_vars:
-            assert torch.equal(g.surf_vars[k], e.surf_vars[k]), k
+            assert torch.equal(g.surf_vars[k].nan_to_num(-1.0), e.surf_vars[k].nan_to_num(-1.0)), k
         for k in e.atmos_vars:
             assert torch.equal(g.atmos_vars[k], e.atmos_vars[k]), k
     # predictions handed out earlier are not overwritten by later replays

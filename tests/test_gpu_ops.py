@@ -269,9 +269,7 @@ def test_unpatchify_matches_oracle():
     for v in range(V):
         lo, s_ = loc[v].to(DEV).contiguous(), sc[v].to(DEV).contiguous()
         keep += [lo, s_]
-        d = L.UnpatchVar(out[v].data_ptr(), lo.data_ptr(), s_.data_ptr(), 1 if v == 1 else 0, v * P * P)
-        d.mod_col0 = -1
-        descs.append(d)
+        descs.append(L.unpatch_var(out[v].data_ptr(), lo.data_ptr(), s_.data_ptr(), 1 if v == 1 else 0, v * P * P))
     L.unpatchify(y.to(DEV), descs, B, CA, Hp, Wp, P)
     torch.cuda.synchronize()
     assert relerr(out.permute(1, 0, 2, 3, 4), ref) < 2e-6

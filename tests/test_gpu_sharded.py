@@ -74,7 +74,7 @@ def make(name, autocast, H=None, W=None):
     case = dict(CASES[name])
     if H:
         case["H"], case["W"] = H, W
-    model = aurora_amd.Aurora(**case["kwargs"], autocast=autocast)
+    model = getattr(aurora_amd, case["cls"])(**case["kwargs"], autocast=autocast)
     model.load_state_dict(helpers.case_state_dict(model, torch.float32))
     model = model.to("cuda").eval()
     surf, static, atmos, lat, lon, times = helpers.case_inputs(case, model.config)
@@ -102,6 +102,22 @@ def test_sharded_equals_unsharded(name, H, W, world, autocast):
     for k, v in ref.atmos_vars.items():
         assert helpers.rel_err(atmos[k].cpu(), v.cpu()) < 2e-6, k
     assert torch.equal(torch.cat([b.metadata.lat for b in bands]), ref.metadata.lat)
+
+
+@pytest.mark.parametrize("name", ["air_pollution", "wave", "stabilised_12h"])
+def test_sharded_variants_equal_unsharded(name):
+    """The variant hooks (difference prediction against the previous state, density / direction
+    channels, water-body mask) address band-local planes correctly."""
+    model, batch = make(name, False, 97, 96)
+    with torch.inference_mode():
+        ref = model.forward(batch)
+        bands, _ = run_virtual_ranks(model, batch, 2)
+    surf, atmos = stitch(bands)
+    assert tuple(surf) == tuple(ref.surf_vars)
+    for got, want in ((surf, ref.surf_vars), (atmos, ref.atmos_vars)):
+        for k, v in want.items():
+            a, b, flipped = helpers.nan_agreement(got[k].cpu(), v.cpu())
+            assert flipped <= 1e-3 and helpers.rel_err(a, b) < 5e-6, (k, flipped)
 
 
 def test_sharded_rollout_stays_distributed():
