@@ -310,6 +310,57 @@ __device__ __forceinline__ void tile_of_block(uint32_t bid, uint32_t nb, uint32_
   }
 }
 
+// Epilogue of the 256 x 256 kernels: a lane owns a row x 16 consecutive features (same ownership as the
+// 128 x 128 kernel) -> bias, activation, fp32 residual, dual-dtype 16-byte stores.
+template <typename T>
+__device__ __forceinline__ void epilogue_256(const LinearArgs& p, f32x4 (&acc)[4][8], int64_t m0, int n0,
+                                             int wm, int wn, int i16, int g) {
+  const int nbase = n0 + wn * 64 + 16 * g;
+  const int n_left = p.N - nbase;
+  if (n_left <= 0) return;
+  float bias_v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) bias_v[t] = (p.bias && t < n_left) ? p.bias[nbase + t] : 0.f;
+  const bool vec = p.vec_store != 0;
+  typedef typename Other<T>::type T2;
+#pragma unroll
+  for (int fm = 0; fm < 8; ++fm) {
+    const int64_t m = m0 + wm * 128 + 16 * fm + i16;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
+      v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
+      v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
+      v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
+    }
+    if (p.act == AURORA_ACT_GELU) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = gelu_for<T>(v[t]);
+    } else if (p.act == AURORA_ACT_SILU) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
+    }
+    if (p.res) {
+      const float* rp = p.res + m * p.ldr + nbase;
+      if (vec && n_left >= 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 rv = reinterpret_cast<const f32x4*>(rp)[q];
+          v[4 * q] += rv.x; v[4 * q + 1] += rv.y; v[4 * q + 2] += rv.z; v[4 * q + 3] += rv.w;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (t < n_left) v[t] += rp[t];
+      }
+    }
+    store16<T>(reinterpret_cast<T*>(p.C) + m * p.ldc + nbase, v, vec, n_left);
+    if (p.C2) store16<T2>(reinterpret_cast<T2*>(p.C2) + m * p.ldc2 + nbase, v, vec, n_left);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256(const LinearArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -423,51 +474,173 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256(const LinearArg
   step(nt - 2, fwA, fxA, fwB, fxB);  // fetches the last stage
   mma_rows(fwB, fxB, 0, 8);
 
-  // ---- epilogue (same ownership as the 128 x 128 kernel: a row x 16 consecutive features) ----
-  const int nbase = n0 + wn * 64 + 16 * g;
-  const int n_left = p.N - nbase;
-  if (n_left <= 0) return;
-  float bias_v[16];
+  epilogue_256<T>(p, acc, m0, n0, wm, wn, i16, g);
+}
+
+
+// =================================================================================================
+// fp32 linear layers on the bf16 matrix pipe: "3 x bf16" operand splitting.
+//
+// gfx950 multiplies bf16 sixteen times faster than fp32 on the matrix cores (v_mfma_f32_16x16x32_bf16:
+// 16 Ki FLOP in 16 cycles; v_mfma_f32_16x16x4_f32: 2 Ki FLOP in 32 cycles).  An fp32 number is EXACTLY the
+// sum of three bf16 numbers (8 + 8 + 8 significand bits, by truncation): a = a_h + a_m + a_l.  Then
+//     a.b = a_h b_h + (a_h b_m + a_m b_h) + (a_h b_l + a_l b_h + a_m b_m) + O(2^-24 |a||b|)
+// and every bf16 x bf16 product is exact in the fp32 accumulator, so six bf16 MFMAs reproduce the fp32
+// product to ~1.2e-7 relative (the three dropped terms), the same order as the 2^-24 rounding an fp32 FMA
+// chain commits per step: an fp32-grade GEMM at 16/6 = 2.7x the fp32 MFMA rate.  (The encoder and decoder of
+// Aurora are fp32 upstream, outside autocast; this keeps them fp32-accurate.  tests/test_gpu_ops.py measures
+// both this kernel and the native-fp32 one against an fp64 product.)
+//
+// Same 256 x 256 tile, LDS-DMA staging, swizzles and epilogue as linear_kernel_256<float>; a K-stage is 16
+// fp32 per row, so two stages (a "pair") make the K = 32 of one bf16 MFMA: lane (row, g) holds fp32
+// k = 4g..4g+3 of both stages, which become its 8 bf16 k-slots (the k order is free as long as both operands
+// agree).  Splitting is done on the fragments in registers: ~36 VALU ops per 8-value fragment, 12 fragments
+// per pair and wave against 192 MFMAs (3072 matrix-pipe cycles), so the VALU work hides under the MFMAs.
+// Ring: pair j is consumed while pair j+1 (64 KiB) is in flight; one barrier per pair.
+// =================================================================================================
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+struct Split3 { u32x4 h, m, l; };
+
+__device__ __forceinline__ void split_pair(uint32_t a0, uint32_t a1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  // top 16 bits of two fp32 -> one packed bf16x2 word (truncation), remainder exact in fp32
+  constexpr uint32_t SEL = 0x07060302u;
+  h = __builtin_amdgcn_perm(a1, a0, SEL);
+  const float r0 = __uint_as_float(a0) - __uint_as_float(a0 & 0xffff0000u);
+  const float r1 = __uint_as_float(a1) - __uint_as_float(a1 & 0xffff0000u);
+  const uint32_t q0 = __float_as_uint(r0), q1 = __float_as_uint(r1);
+  m = __builtin_amdgcn_perm(q1, q0, SEL);
+  const float s0 = r0 - __uint_as_float(q0 & 0xffff0000u);
+  const float s1 = r1 - __uint_as_float(q1 & 0xffff0000u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), SEL);
+}
+
+__device__ __forceinline__ Split3 split8(u32x4 a, u32x4 b) {
+  uint32_t h[4], m[4], l[4];
+  split_pair(a.x, a.y, h[0], m[0], l[0]);
+  split_pair(a.z, a.w, h[1], m[1], l[1]);
+  split_pair(b.x, b.y, h[2], m[2], l[2]);
+  split_pair(b.z, b.w, h[3], m[3], l[3]);
+  return Split3{u32x4{h[0], h[1], h[2], h[3]}, u32x4{m[0], m[1], m[2], m[3]}, u32x4{l[0], l[1], l[2], l[3]}};
+}
+
+__device__ __forceinline__ f32x4 mma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                 c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const LinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  uint32_t tile_m, tile_n;
+  tile_of_block(blockIdx.x, (uint32_t)p.n_blocks, (uint32_t)(p.n_blocks / p.tiles_n), (uint32_t)p.tiles_n, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM2;
+  const int n0 = (int)tile_n * BN2;
+
+  const char* src_x[2];
+  const char* src_w[2];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) bias_v[t] = (p.bias && t < n_left) ? p.bias[nbase + t] : 0.f;
-  const bool vec = p.vec_store != 0;
-  typedef typename Other<T>::type T2;
+  for (int r = 0; r < 2; ++r) {
+    const int id = r * THREADS2 + tid;
+    const int row = id >> 2, c = id & 3;
+    int64_t gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + row;
+    gn = gn < p.N ? gn : p.N - 1;
+    src_x[r] = p.A + gm * p.lda_b + ((c ^ swz2_x(row)) << 4);
+    src_w[r] = p.W + (int64_t)gn * p.ldw_b + ((c ^ swz2_w(row)) << 4);
+  }
+  auto stage = [&](int kt) {
+    const int64_t koff = (int64_t)kt * ROW2;
+    char* base = smem + (kt & (NSTAGE2 - 1)) * STAGE2;
 #pragma unroll
-  for (int fm = 0; fm < 8; ++fm) {
-    const int64_t m = m0 + wm * 128 + 16 * fm + i16;
-    if (m >= p.M) continue;
-    float v[16];
-#pragma unroll
-    for (int fn = 0; fn < 4; ++fn) {
-      v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
-      v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
-      v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
-      v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
+    for (int r = 0; r < 2; ++r) {
+      const int off = (r * THREADS2 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[r] + koff),
+                                       (lds_ptr_t)(base + off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
+                                       (lds_ptr_t)(base + OPER2 + off), 16, 0, 0);
     }
-    if (p.act == AURORA_ACT_GELU) {
+  };
+
+  const int i16 = lane & 15, g = lane >> 4;
+  int off_x[8], off_w[4];
 #pragma unroll
-      for (int t = 0; t < 16; ++t) v[t] = gelu_for<T>(v[t]);
-    } else if (p.act == AURORA_ACT_SILU) {
+  for (int f = 0; f < 8; ++f) {
+    const int row = wm * 128 + 16 * f + i16;
+    off_x[f] = row * ROW2 + ((g ^ swz2_x(row)) << 4);
+  }
 #pragma unroll
-      for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
+  for (int f = 0; f < 4; ++f) {
+    const int row = wn * 64 + 16 * (i16 >> 2) + 4 * f + (i16 & 3);
+    off_w[f] = OPER2 + row * ROW2 + ((g ^ swz2_w(row)) << 4);
+  }
+
+  f32x4 acc[4][8];  // [fn][fm]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int np = p.k_tiles >> 1;  // pairs of stages (k_tiles is even)
+  stage(0);
+  stage(1);
+  if (np > 1) {
+    stage(2);
+    stage(3);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int j = 0; j < np; ++j) {
+    const char* bufa = smem + ((2 * j) & (NSTAGE2 - 1)) * STAGE2;
+    const char* bufb = smem + ((2 * j + 1) & (NSTAGE2 - 1)) * STAGE2;
+    Split3 w[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+      w[f] = split8(*reinterpret_cast<const u32x4*>(bufa + off_w[f]), *reinterpret_cast<const u32x4*>(bufb + off_w[f]));
+    u32x4 ra = *reinterpret_cast<const u32x4*>(bufa + off_x[0]);
+    u32x4 rb = *reinterpret_cast<const u32x4*>(bufb + off_x[0]);
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm) {
+      const Split3 x = split8(ra, rb);
+      if (fm + 1 < 8) {
+        ra = *reinterpret_cast<const u32x4*>(bufa + off_x[fm + 1]);
+        rb = *reinterpret_cast<const u32x4*>(bufb + off_x[fm + 1]);
+      }
+      // smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].l, x.h, acc[fn][fm]);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.l, acc[fn][fm]);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].m, x.m, acc[fn][fm]);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].m, x.h, acc[fn][fm]);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.m, acc[fn][fm]);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.h, acc[fn][fm]);
     }
-    if (p.res) {
-      const float* rp = p.res + m * p.ldr + nbase;
-      if (vec && n_left >= 16) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 rv = reinterpret_cast<const f32x4*>(rp)[q];
-          v[4 * q] += rv.x; v[4 * q + 1] += rv.y; v[4 * q + 2] += rv.z; v[4 * q + 3] += rv.w;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-          if (t < n_left) v[t] += rp[t];
+    if (j + 1 < np) {
+      // RAW: my pieces of pair j+1 (issued a whole pair ago) have landed; WAR: everyone has read pair j.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (j + 2 < np) {
+        stage(2 * j + 4);
+        stage(2 * j + 5);
       }
     }
-    store16<T>(reinterpret_cast<T*>(p.C) + m * p.ldc + nbase, v, vec, n_left);
-    if (p.C2) store16<T2>(reinterpret_cast<T2*>(p.C2) + m * p.ldc2 + nbase, v, vec, n_left);
   }
+  epilogue_256<float>(p, acc, m0, n0, wm, wn, i16, g);
 }
 
 }  // namespace
@@ -475,6 +648,24 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256(const LinearArg
 }  // namespace aurora
 
 using namespace aurora;
+
+namespace {
+// 0: native fp32 MFMA (v_mfma_f32_16x16x4_f32); 1: 3 x bf16 operand splitting (default).
+int g_f32_mode = -1;
+int f32_mode() {
+  if (g_f32_mode < 0) {
+    const char* e = getenv("AURORA_F32_GEMM");
+    g_f32_mode = (e && e[0] == 'n') ? 0 : 1;   // AURORA_F32_GEMM=native
+  }
+  return g_f32_mode;
+}
+}  // namespace
+
+extern "C" int aurora_hip_set_f32_gemm(int mode) {
+  const int prev = f32_mode();
+  if (mode == 0 || mode == 1) g_f32_mode = mode;
+  return prev;
+}
 
 extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int64_t ldw,
                                  const float* bias, void* C, int64_t ldc, void* C2, int64_t ldc2,
@@ -493,7 +684,10 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
                    "linear: bad output strides");
 
   // Big backbone shapes take the 256 x 256 ring kernel; everything else the 128 x 128 one.
-  const bool big = M >= 1024 && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
+  // (fp32 in split mode: the kernel choice must not depend on M, or a latitude band of a sharded model
+  // would round differently from the same rows of the un-sharded one.)
+  const bool split = dtype == AURORA_F32 && f32_mode() == 1;
+  const bool big = (M >= 1024 || split) && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
   const int bm = big ? BM2 : BM, bn = big ? BN2 : BN, rowb = big ? ROW2 : ROW_BYTES;
   LinearArgs p;
   p.A = (const char*)A; p.lda_b = lda * es;
@@ -517,10 +711,13 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
     (void)hipFuncSetAttribute((const void*)linear_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     attr_done = true;
   }
   if (big) {
-    if (dtype == AURORA_F32)
+    if (split)
+      hipLaunchKernelGGL(linear_kernel_256_f32x3, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    else if (dtype == AURORA_F32)
       hipLaunchKernelGGL(linear_kernel_256<float>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else
       hipLaunchKernelGGL(linear_kernel_256<bf16_t>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);

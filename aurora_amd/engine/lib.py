@@ -48,6 +48,7 @@ def unpatch_var(dst: int, loc: int, scale: int, clamp_min0: int, col0: int) -> U
 _SIGNATURES = {
     "aurora_hip_version": (c_int, []),
     "aurora_hip_last_error": (ctypes.c_char_p, []),
+    "aurora_hip_set_f32_gemm": (c_int, [c_int]),
     "aurora_hip_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                   c_int, c_void_p]),
@@ -186,6 +187,11 @@ class _Timed:
 
 
 # ---- wrappers ------------------------------------------------------------------------------
+def set_f32_gemm(mode: int) -> int:
+    """0 = native fp32 MFMA, 1 = exact 3 x bf16 operand splitting (default); returns the previous mode."""
+    return load().aurora_hip_set_f32_gemm(mode)
+
+
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
            out2: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            act: int = ACT_NONE, n: Optional[int] = None, k: Optional[int] = None) -> torch.Tensor:

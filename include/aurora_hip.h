@@ -53,6 +53,14 @@ int aurora_hip_linear(const void* A, int64_t lda, const void* W, int64_t ldw, co
                       const float* residual, int64_t ldr,
                       int64_t M, int N, int K, int dtype, int act, void* stream);
 
+/* How large fp32 linears (M >= 1024, N % 256 == 0) are multiplied.  1 (default): every fp32 operand is
+ * split exactly into three bf16 terms and six bf16 MFMAs per K-slab reproduce the fp32 product to
+ * ~1e-7 relative (fp32-grade, 2.7x the fp32 MFMA rate).  0: native v_mfma_f32_16x16x4_f32 FMA chains
+ * (also selected by the environment variable AURORA_F32_GEMM=native).  Returns the previous mode;
+ * any other argument only queries.  The reference's counterpart is the fp32 F.linear outside
+ * autocast (encoder.py / decoder.py, aurora.py:322-349). */
+int aurora_hip_set_f32_gemm(int mode);
+
 /* ---- 3D shifted-window attention core ------------------------------------------------------
  * For every window w and head h: O = softmax(Q K^T / sqrt(hd) + mask) V over the window's
  * `win_tokens` (<= 144) tokens.  qkv: [B][L][3*D] with columns q | k | v, each head-major

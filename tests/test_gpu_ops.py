@@ -59,6 +59,34 @@ def test_linear_fp32(M, N, K, act):
         assert torch.isnan(out[:, N:]).all()  # padding columns untouched
 
 
+@pytest.mark.parametrize("M,N,K", [(1030, 256, 32), (2050, 512, 160), (1500, 768, 512), (4099, 1024, 2048)])
+def test_linear_fp32_by_bf16_splitting_is_fp32_grade(M, N, K):
+    """Large fp32 linears run as six bf16 MFMAs over an exact 3-way operand split; their error against an
+    fp64 product must be of the order of the native fp32 MFMA kernel's (both are measured here, relative to
+    the natural scale sum_k |a||w|), on operands spanning six decades."""
+    L = lib()
+    g = torch.Generator().manual_seed(11)
+    mag = lambda *sh: 10.0 ** (torch.rand(*sh, generator=g, dtype=torch.float64) * 6 - 3)  # noqa: E731
+    a = (rnd(M, K, seed=1) * mag(M, K)).float()
+    w = (rnd(N, K, seed=2) * mag(N, K)).float()
+    ref = a.double() @ w.double().T
+    scale = a.double().abs() @ w.double().abs().T
+    err = {}
+    prev = L.set_f32_gemm(-1)
+    try:
+        for mode in (0, 1):
+            L.set_f32_gemm(mode)
+            out = torch.empty((M, N), device=DEV)
+            L.linear(a.to(DEV), w.to(DEV), None, out)
+            torch.cuda.synchronize()
+            err[mode] = ((out.double().cpu() - ref).abs() / scale).max().item()
+    finally:
+        L.set_f32_gemm(prev)
+    print(f"fp32 linear {M}x{N}x{K}: native MFMA err {err[0]:.2e}, 3xbf16 split err {err[1]:.2e}")
+    assert err[0] < 2e-6, err
+    assert err[1] < 2e-6 and err[1] < 2 * err[0] + 1e-7, err
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (130, 64, 64), (1000, 1536, 512), (129, 80, 2048),
                                    # the 256 x 256 ring kernel: 2, 4, 6 and 32 stages, ragged M
                                    (1030, 256, 64), (1500, 512, 128), (1100, 768, 192), (4099, 1536, 1024)])

@@ -15,6 +15,9 @@ SHAPES = [  # (name, M, N, K, weight in the step)
     ("s2.qkv", 16200, 6144, 2048, 16), ("s2.proj", 16200, 2048, 2048, 16),
     ("s2.fc1", 16200, 8192, 2048, 16), ("s2.fc2", 16200, 2048, 8192, 16),
     ("sq4096", 4096, 4096, 4096, 0), ("sq8192", 8192, 8192, 8192, 0),
+    # fp32 encoder / decoder linears (run with `f32`): level aggregation and level decoder
+    ("e.kv", 907200, 1024, 512, 0), ("d.proj", 842400, 512, 512, 0), ("d.fc1", 842400, 2048, 512, 0),
+    ("d.fc2", 842400, 512, 2048, 0), ("d.kv", 194400, 1024, 1024, 0), ("e.embed", 842400, 512, 160, 0),
 ]
 dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
 if len(sys.argv) > 2:  # restrict to the named shapes
@@ -41,4 +44,5 @@ for name, M, N, K, wt in SHAPES:
     tot_fl += fl * wt
     print(f"{name:8s} M={M:6d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
     del a, w, out
-print(f"weighted backbone: {tot_ms:.1f} ms/step, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
+if tot_ms:
+    print(f"weighted backbone: {tot_ms:.1f} ms/step, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
