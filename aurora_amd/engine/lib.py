@@ -9,6 +9,7 @@ hard error -- there is no fallback implementation in this package.
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_float, c_int, c_int32, c_int64, c_void_p
 from pathlib import Path
 from typing import Optional
@@ -95,7 +96,8 @@ def load() -> ctypes.CDLL:
                 f"{_LIB_PATH} is missing: build it with `python -m aurora_amd.build` "
                 "(hipcc, gfx950). aurora_amd has no fallback compute path."
             )
-        lib = ctypes.CDLL(str(_LIB_PATH))
+        # (kernel experiments: AURORA_HIP_LIB points at an alternative build of the same ABI)
+        lib = ctypes.CDLL(os.environ.get("AURORA_HIP_LIB") or str(_LIB_PATH))
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args

@@ -89,7 +89,9 @@ def test_linear_fp32_by_bf16_splitting_is_fp32_grade(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (130, 64, 64), (1000, 1536, 512), (129, 80, 2048),
                                    # the 256 x 256 ring kernel: 2, 4, 6 and 32 stages, ragged M
-                                   (1030, 256, 64), (1500, 512, 128), (1100, 768, 192), (4099, 1536, 1024)])
+                                   (1030, 256, 64), (1500, 512, 128), (1100, 768, 192), (4099, 1536, 1024),
+                                   # K <= 512: the persistent streamed-weights kernel; 516 tiles on 256 CUs, ragged M
+                                   (66001, 512, 256), (33000, 1024, 512)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_linear_bf16(M, N, K, act):
     L = lib()
