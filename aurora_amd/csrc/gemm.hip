@@ -282,7 +282,6 @@ __global__ __launch_bounds__(THREADS, 2) void linear_kernel(const LinearArgs p) 
 constexpr int BM2 = 256, BN2 = 256, ROW2 = 64, THREADS2 = 512, NSTAGE2 = 4;
 constexpr int OPER2 = 256 * ROW2;      // 16 KiB per operand per stage
 constexpr int STAGE2 = 2 * OPER2;      // 32 KiB per stage
-constexpr int HALF_LDS = 3 * (OPER2 + OPER2 / 2);  // 256 x 128 variant: 3 stages of 24 KiB
 
 __device__ __forceinline__ int swz2(int a) { return ((a >> 1) & 1) * 3; }
 __device__ __forceinline__ int swz2_x(int row) { return swz2((row >> 2) & 3); }
@@ -412,10 +411,66 @@ __device__ __forceinline__ void epilogue_256_bf16_coalesced(const LinearArgs& p,
   }
 }
 
-// WN = number of wave columns: 4 -> 256 x 256 tile, 512 threads, one workgroup per CU (4-stage ring, 128 KiB);
-//                              2 -> 256 x 128 tile, 256 threads, TWO workgroups per CU (3-stage ring, 72 KiB each):
-// the two workgroups run out of phase, so one's prologue / epilogue / barrier waits are covered by the other's
-// MFMAs -- the better choice for short K, where a tile is mostly prologue and epilogue.
+// fp32 outputs, same idea in two halves (a wave's 128 x 64 fp32 results are 32 KiB, its share of the dead ring
+// 16 KiB): rows of 256 bytes, pieces XOR-swizzled by (row & 7); a store instruction writes 4 whole row segments.
+__device__ __forceinline__ void epilogue_256_f32_coalesced(const LinearArgs& p, f32x4 (&acc)[4][8], int64_t m0,
+                                                           int n0, int wm, int wn, int wave, int lane, char* smem) {
+  const int i16 = lane & 15, g = lane >> 4;
+  char* mine = smem + wave * 16384;
+  const int nbase = n0 + wn * 64 + 16 * g;
+  float bias_v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
+  const int rr = lane >> 4, cc = lane & 15;
+  float* cbase = reinterpret_cast<float*>(p.C) + n0 + wn * 64 + cc * 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int fm = 4 * half + f;
+      float v[16];
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) {
+        v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
+        v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
+        v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
+        v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
+      }
+      if (p.act == AURORA_ACT_GELU) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = gelu_for<float>(v[t]);
+      } else if (p.act == AURORA_ACT_SILU) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
+      }
+      if (p.res) {
+        const int64_t m = m0 + wm * 128 + 16 * fm + i16;
+        const float* rp = p.res + (m < p.M ? m : p.M - 1) * p.ldr + nbase;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 rv = reinterpret_cast<const f32x4*>(rp)[q];
+          v[4 * q] += rv.x; v[4 * q + 1] += rv.y; v[4 * q + 2] += rv.z; v[4 * q + 3] += rv.w;
+        }
+      }
+      const int row = 16 * f + i16, sw = row & 7;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(mine + row * 256 + (((4 * g + q) ^ sw) << 4)) =
+            f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + rr;
+      const f32x4 d = *reinterpret_cast<const f32x4*>(mine + row * 256 + ((cc ^ (row & 7)) << 4));
+      const int64_t m = m0 + wm * 128 + 64 * half + row;
+      if (m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<f32x4*>(cbase + m * p.ldc));
+    }
+  }
+}
+
+// WN = number of wave columns: 4 -> 256 x 256 tile, 512 threads, one workgroup per CU (4-stage ring, 128 KiB) -- the
+// one in use.  (WN = 2, NST = 3 is a 256 x 128 tile with two workgroups per CU; measured 5-15 % slower on every
+// backbone shape -- co-resident workgroups start together and stay in phase -- and not instantiated.)
 template <typename T, int WN, int NST>
 __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArgs p) {
   constexpr int NTHR = 128 * WN;
@@ -556,271 +611,16 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
       epilogue_256_bf16_coalesced(p, acc, m0, n0, wm, wn, wave, lane, smem);
       return;
     }
+  } else if constexpr (WN == 4) {
+    if (p.C2 == nullptr && p.vec_store) {
+      __syncthreads();
+      epilogue_256_f32_coalesced(p, acc, m0, n0, wm, wn, wave, lane, smem);
+      return;
+    }
   }
   epilogue_256<T>(p, acc, m0, n0, wm, wn, i16, g);
 }
 
-
-// =================================================================================================
-// Persistent "streamed-weights" kernel for bf16 linears with a plain bf16 output (every backbone linear).
-//
-// What the measurements say about the ring kernel above (tools/probes/l1_probe.hip, tools/gemm_ksweep.py):
-//   * its main loop delivers 32 KiB of operands per K-stage in ~1900 cycles = 17 B/clk/CU, against 1024 cycles
-//     of MFMA work: it is bound by the vector-memory front end, because a K-stage row is 64 bytes, HALF a cache
-//     line -- LDS-DMA instructions that fetch 16 rows x 64 B run at 15 B/clk/CU, instructions that fetch 8 rows
-//     x 128 B (whole lines) at 59 B/clk/CU, both from L2;
-//   * with 128-byte rows a 256 x 256 tile needs 64 KiB per stage, so only two stages fit in LDS and the ring is
-//     too shallow to hide L2 latency (tried: 1.0 PFLOP/s at K = 4096 against 1.15 for the 64-byte ring);
-//   * a tile's fixed cost (workgroup launch, un-hidden prologue, epilogue + store drain) is ~9.5 us, as much as
-//     the MFMA time of a K = 512 tile.
-// So: weights do not go through LDS at all.  They are static per call, so a pre-pass (pack_w_kernel) rewrites
-// W[N][K] into MFMA-fragment order -- the 4 KiB a wave needs per K-stage become one contiguous run, fetched
-// with four 1 KiB global_load_dwordx4 straight into registers one stage ahead.  LDS then holds only the
-// activation tile, 256 rows x 128 B = 32 KiB per stage of K = 64: whole lines AND a 4-slot ring (3 stages in
-// flight).  The 8 waves sit side by side along N (wave tile 256 x 32, acc[2][16]); every wave reads all 256
-// activation rows from LDS (ds_read_b128 runs at 256 B/clk/CU, 50 % busy) and no weight fragment is loaded twice.
-// One persistent workgroup per CU walks over its tiles; the ring never drains between tiles.
-//
-// vmcnt bookkeeping: operations are issued in groups of 4 per lane (a W stage = 4 loads, an A stage = 4 LDS-DMA
-// pieces).  Loads return in order among loads, so "everything older than the g youngest groups has landed" is
-// `s_waitcnt vmcnt(4 g)`; the epilogue's stores are not counted in g, which only makes a wait stronger.
-// =================================================================================================
-constexpr int SW_STAGE = 256 * 128;                 // activation tile per stage (K = 64 bf16)
-constexpr int SW_SLOTS = 4;
-constexpr int SW_LDS = SW_SLOTS * SW_STAGE;         // 128 KiB ring
-constexpr int SW_LDS_TOTAL = SW_LDS + 2 * 16384;    // + two 16 KiB epilogue slabs = 160 KiB
-
-// Wp[((tn * KT + kt) * 8 + w) * 4 + ks * 2 + fn][lane] (16 bytes each)
-//   = W[256 tn + 32 w + 8 (i >> 2) + 4 fn + (i & 3)][64 kt + 32 ks + 8 g .. + 8],   lane = (i = lane & 15, g = lane >> 4)
-// i.e. MFMA A-operand fragments, with the rows interleaved such that lane (j, g) of the C^T fragments ends up
-// with the 8 consecutive features 8 g .. 8 g + 7 of its wave's 32 (fn = 0, 1 x 4 registers).
-__global__ __launch_bounds__(256) void pack_w_kernel(const bf16_t* __restrict__ W, int64_t ldw, u32x4* __restrict__ Wp,
-                                                     int KT, int64_t n_pieces) {
-  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (id >= n_pieces) return;
-  const int lane = (int)(id & 63);
-  const int frag = (int)((id >> 6) & 3), w = (int)((id >> 8) & 7);
-  const int64_t st = id >> 11;                     // tn * KT + kt
-  const int kt = (int)(st % KT);
-  const int64_t tn = st / KT;
-  const int i = lane & 15, g = lane >> 4, ks = frag >> 1, fn = frag & 1;
-  const int64_t n = 256 * tn + 32 * w + 8 * (i >> 2) + 4 * fn + (i & 3);
-  Wp[id] = *reinterpret_cast<const u32x4*>(W + n * ldw + 64 * kt + 32 * ks + 8 * g);
-}
-
-__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_sw(const LinearArgs p, const u32x4* __restrict__ Wp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i16 = lane & 15, g = lane >> 4;
-  const uint32_t n_tiles = (uint32_t)p.n_blocks, tiles_n = (uint32_t)p.tiles_n, tiles_m = n_tiles / tiles_n;
-  const int nt = p.k_tiles;   // stages of K = 64 per tile
-  const uint32_t my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;   // >= 1 (grid <= n_tiles)
-  const int S = (int)my_tiles * nt;
-
-  // ---- activation stream (LDS-DMA), 4 pieces per lane and stage ----
-  const char* a_base = nullptr;   // p.A + m0 * lda (uniform)
-  int last_row = 0;
-  const int row0 = tid >> 3;      // piece r covers tile row 64 r + row0, 16-byte chunk tid & 7 (swizzled at the source)
-  const uint32_t cx = (uint32_t)(((tid & 7) ^ swz_x(row0)) << 4);
-  uint32_t a_tile = blockIdx.x;
-  int a_kt = 0, a_issued = 0;
-  auto a_set = [&](uint32_t t) {
-    uint32_t tm, tn;
-    tile_of_block(t, n_tiles, tiles_m, tiles_n, tm, tn);
-    const int64_t m0 = (int64_t)tm * BM2;
-    a_base = p.A + m0 * p.lda_b;
-    last_row = (int)(p.M - 1 - m0 < BM2 - 1 ? p.M - 1 - m0 : BM2 - 1);   // rows past M re-read row M-1
-  };
-  auto a_piece = [&](int r) {
-    const int row = row0 + 64 * r;
-    const uint32_t vo = (uint32_t)(row < last_row ? row : last_row) * (uint32_t)p.lda_b + cx;
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(a_base + (int64_t)a_kt * 128 + vo),
-        (lds_ptr_t)(smem + (a_issued & (SW_SLOTS - 1)) * SW_STAGE + (r * THREADS2 + wave * 64) * 16), 16, 0, 0);
-  };
-  auto a_done = [&]() {
-    ++a_issued;
-    if (++a_kt == nt) {
-      a_kt = 0;
-      a_tile += gridDim.x;
-      if (a_tile < n_tiles) a_set(a_tile);
-    }
-  };
-
-  // ---- weight stream (global -> registers), one stage = 4 fragments [ks * 2 + fn] ----
-  uint32_t w_tile = blockIdx.x;
-  int w_kt = 0;
-  const u32x4* w_ptr = nullptr;   // fragments of (w_tile, kt = 0) for this wave and lane
-  auto w_set = [&](uint32_t t) {
-    uint32_t tm, tn;
-    tile_of_block(t, n_tiles, tiles_m, tiles_n, tm, tn);
-    w_ptr = Wp + ((int64_t)tn * nt * 8 + wave) * 256 + lane;
-  };
-  auto w_load = [&](u32x4 (&w)[4]) {   // next stage of the stream (caller guarantees there is one)
-    const u32x4* q = w_ptr + (int64_t)w_kt * (8 * 256);
-#pragma unroll
-    for (int f = 0; f < 4; ++f) w[f] = q[f * 64];
-    if (++w_kt == nt) {
-      w_kt = 0;
-      w_tile += gridDim.x;
-      if (w_tile < n_tiles) w_set(w_tile);
-    }
-  };
-  auto wait_groups = [&](int younger) {   // everything older than the `younger` youngest groups has landed
-    if (younger >= 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (younger == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (younger == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-
-  // ---- multiply side ----
-  const int off_x0 = i16 * 128 + ((g ^ swz_x(i16)) << 4);   // fragment row 16 fm + i16: + fm * 2048; ks: ^ 64
-  auto lds_x = [&](int s, int ks, int fm) {
-    return *reinterpret_cast<const u32x4*>(smem + (s & (SW_SLOTS - 1)) * SW_STAGE + (off_x0 ^ (ks << 6)) + fm * 2048);
-  };
-  f32x4 acc[2][16];  // [fn][fm]
-  u32x4 X[8], Wa[4], Wb[4];
-  // A stage is multiplied in four phases of 16 MFMAs: (ks, half) = (0, lo) (0, hi) (1, lo) (1, hi), where lo / hi
-  // are fragment rows 0-7 / 8-15.  The activation fragments live in ONE set of 8 registers-quads that is refilled
-  // row by row: once the two MFMAs of a row are issued, the same row of the NEXT phase is requested into the same
-  // registers (needed a whole phase later).  Weights: 4 fragments per stage, double-buffered across stages.
-  auto mma_row = [&](u32x4 (&w)[4], int ks, int r, int fm) {
-    acc[0][fm] = Mma<bf16_t>::run(w[2 * ks], X[r], acc[0][fm]);
-    acc[1][fm] = Mma<bf16_t>::run(w[2 * ks + 1], X[r], acc[1][fm]);
-  };
-  auto phase = [&](u32x4 (&w)[4], int s, int ks, int hi) {   // phases 0..2: the next phase is in the same slot
-    const int nks = hi ? ks + 1 : ks, nhi = hi ^ 1;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      mma_row(w, ks, r, 8 * hi + r);
-      X[r] = lds_x(s, nks, 8 * nhi + r);
-      if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  // Last phase (1, hi): refill from (s + 1, 0, lo) in the next slot.  Rows 0-1 need only registers and cover the
-  // synchronisation: stage s+1 has landed (issued three stages ago), every wave is done reading stage s (its last
-  // reads were the refills of phase 2), whose slot takes stage s+4 -- the 4 pieces go between MFMA rows.  `reload`
-  // is false on a tile's last stage (the next tile's first fragments are read after the epilogue).
-  auto phase_sync = [&](u32x4 (&w)[4], int s) {
-    mma_row(w, 1, 0, 8);
-    mma_row(w, 1, 1, 9);
-    __builtin_amdgcn_sched_barrier(0);
-    bool refill = false;
-    if (s + 1 < S) {
-      // Groups issued after A(s+1) [in stage s-3]: W(s-1), A(s+2), W(s), A(s+3), W(s+1); the first SW_SLOTS stages
-      // were drained completely in the prologue.
-      if (s + 1 >= SW_SLOTS) wait_groups(3 + (s + 2 < S) + (s + 3 < S));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      refill = a_issued < S;
-    }
-    // (after the very last stage the refills read a stale slot; the values are never used)
-    X[0] = lds_x(s + 1, 0, 0);
-    X[1] = lds_x(s + 1, 0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 2; r < 8; ++r) {
-      mma_row(w, 1, r, 8 + r);
-      if (refill && r < 6) a_piece(r - 2);
-      X[r] = lds_x(s + 1, 0, r);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (refill) a_done();
-    if (s + 1 < S) wait_groups(refill ? 1 : 0);   // W(s+1) [issued in phase 0] has landed; only A(s+4) may be younger
-  };
-  auto load_first = [&](int s) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) X[r] = lds_x(s, 0, r);
-  };
-
-  a_set(a_tile);
-  w_set(w_tile);
-  for (int st = 0; st < SW_SLOTS && st < S; ++st) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a_piece(r);
-    a_done();
-  }
-  w_load(Wa);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  load_first(0);
-
-  int s = 0;
-  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b2 = 0; b2 < 16; ++b2) acc[a][b2] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nt; ++kt, ++s) {
-      if (s + 1 < S) w_load(Wb);   // weights of the next stage, one stage ahead
-      phase(Wa, s, 0, 0);
-      phase(Wa, s, 0, 1);
-      phase(Wa, s, 1, 0);
-      phase_sync(Wa, s);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) Wa[f] = Wb[f];
-    }
-
-    // ---- epilogue ----
-    // Lane (j, g) owns rows 16 fm + j, features 8 g .. 8 g + 7 of its wave's 32: written directly that is 16 rows x
-    // 64 bytes per store instruction, a pattern the CU's store path runs at 15 B/clk (3.6 us per tile even on an
-    // otherwise idle chip; tools/probes/l1_probe.hip) against 56 B/clk for whole contiguous rows.  So the 8 waves
-    // assemble 32 rows x 512 B at a time in a spare LDS slab (two slabs alternate: one barrier per pass) and
-    // every store instruction then writes 2 whole rows of the tile.  Slab pieces are XOR-swizzled (piece ^ (row & 7)):
-    // conflict-free for the b128 writes (8 rows per lane group) and reads (pieces 0..31 of one row).
-    uint32_t tm, tn;
-    tile_of_block(tile, n_tiles, tiles_m, tiles_n, tm, tn);
-    const int64_t m0 = (int64_t)tm * BM2;
-    const int n0 = (int)tn * BN2;
-    float bias_v[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) bias_v[t] = p.bias ? p.bias[n0 + wave * 32 + 8 * g + t] : 0.f;
-    bf16_t* cbase = reinterpret_cast<bf16_t*>(p.C) + n0 + (lane & 31) * 8;
-#pragma unroll
-    for (int pass = 0; pass < 8; ++pass) {
-      char* slab = smem + SW_LDS + (pass & 1) * 16384;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int fm = 2 * pass + h;
-        float v[8];
-#pragma unroll
-        for (int fn = 0; fn < 2; ++fn) {
-          v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
-          v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
-          v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
-          v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
-        }
-        if (p.act == AURORA_ACT_GELU) {
-#pragma unroll
-          for (int t = 0; t < 8; ++t) v[t] = gelu_for<bf16_t>(v[t]);
-        } else if (p.act == AURORA_ACT_SILU) {
-#pragma unroll
-          for (int t = 0; t < 8; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
-        }
-        const int row = 16 * h + i16;
-        *reinterpret_cast<u32x4*>(slab + row * 512 + (((4 * wave + g) ^ (row & 7)) << 4)) =
-            u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int row = 4 * wave + 2 * q + (lane >> 5);
-        const u32x4 d = *reinterpret_cast<const u32x4*>(slab + row * 512 + (((lane & 31) ^ (row & 7)) << 4));
-        const int64_t m = m0 + 32 * pass + row;
-        // (non-temporal: the result is not re-read by this kernel and should not displace the operand panels in L2)
-        if (m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
-      }
-    }
-  }
-}
 
 // =================================================================================================
 // fp32 linear layers on the bf16 matrix pipe: "3 x bf16" operand splitting.
@@ -984,6 +784,11 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
       }
     }
   }
+  if (p.C2 == nullptr && p.vec_store) {   // (uniform)
+    __syncthreads();   // every wave is done with the ring
+    epilogue_256_f32_coalesced(p, acc, m0, n0, wm, wn, wave, lane, smem);
+    return;
+  }
   epilogue_256<float>(p, acc, m0, n0, wm, wn, i16, g);
 }
 
@@ -1004,30 +809,6 @@ int f32_mode() {
   return g_f32_mode;
 }
 
-// Workspace for the fragment-ordered copy of a weight matrix (rewritten by every call; stream-ordered: the pack
-// kernel and the GEMM that reads it are launched back to back on the caller's stream, so calls on ONE stream --
-// what the engine does -- are safe; concurrent streams would race on it).  The first call allocates it, which is
-// not legal inside a stream capture: callers that capture warm up eagerly first (the engine does).
-void* packed_weight_buffer(size_t bytes) {
-  static void* buf = nullptr;
-  static bool tried = false;
-  constexpr size_t CAP = (size_t)128 << 20;   // 8192 x 8192 bf16; allocated once and never moved, so that a
-  if (!tried) {                               // captured hipGraph can never hold a stale pointer
-    tried = true;
-    if (hipMalloc(&buf, CAP) != hipSuccess) buf = nullptr;
-  }
-  return bytes <= CAP ? buf : nullptr;
-}
-int device_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    (void)hipGetDevice(&dev);
-    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  return n;
-}
 }  // namespace
 
 extern "C" int aurora_hip_set_f32_gemm(int mode) {
@@ -1057,8 +838,6 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
   // would round differently from the same rows of the un-sharded one.)
   const bool split = dtype == AURORA_F32 && f32_mode() == 1;
   const bool big = (M >= 1024 || split) && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
-  // 256 x 128 tiles with two workgroups per CU when K is short (few stages per tile) -- measured, tools/gemm_bench.py
-  const bool half = false;
   const int bm = big ? BM2 : BM, bn = big ? BN2 : BN, rowb = big ? ROW2 : ROW_BYTES;
   LinearArgs p;
   p.A = (const char*)A; p.lda_b = lda * es;
@@ -1076,18 +855,6 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
   AURORA_CHECK_ARG(p.n_blocks < (int64_t)1 << 31, "linear: too many tiles");
 
   dim3 grid((unsigned)p.n_blocks);
-  // Streamed-weights persistent kernel: bf16, plain bf16 output (AURORA_GEMM_SW=0 falls back to the ring kernel).
-  static const char* sw_env = getenv("AURORA_GEMM_SW");
-  // Measured (tools/gemm_bench.py): it wins for K <= 512, where a tile is mostly prologue / epilogue; for longer K the
-  // ring kernel's wider wave tile (fewer LDS reads per MFMA) wins.  AURORA_GEMM_SW=0 / 1 forces never / always.
-  bool sw = big && dtype == AURORA_BF16 && C2 == nullptr && residual == nullptr && vec && K % 64 == 0 &&
-            lda * es * 256 < ((int64_t)1 << 31) && !(sw_env && sw_env[0] == '0') &&
-            (K <= 512 || (sw_env && sw_env[0] == '1'));
-  u32x4* Wp = nullptr;
-  if (sw) {
-    Wp = reinterpret_cast<u32x4*>(packed_weight_buffer((size_t)N * K * 2));
-    sw = Wp != nullptr;
-  }
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)linear_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
@@ -1095,22 +862,11 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<float, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_sw, hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS_TOTAL);
     attr_done = true;
   }
   if (big) {
     if (split)
       hipLaunchKernelGGL(linear_kernel_256_f32x3, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-    else if (sw) {
-      const int KT = K / 64;
-      const int64_t n_pieces = (int64_t)(N / 256) * KT * 8 * 4 * 64;   // 16-byte pieces = N * K / 8
-      hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n_pieces + 255) / 256)), dim3(256), 0, as_stream(stream),
-                         (const bf16_t*)W, ldw, Wp, KT, n_pieces);
-      p.k_tiles = KT;
-      const unsigned cus = (unsigned)device_cus();
-      hipLaunchKernelGGL(linear_kernel_sw, dim3((unsigned)(p.n_blocks < cus ? p.n_blocks : cus)), dim3(THREADS2), SW_LDS_TOTAL,
-                         as_stream(stream), p, (const u32x4*)Wp);
-    }
     else if (dtype == AURORA_F32)
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else
