@@ -68,6 +68,11 @@ class Exchange:
 
     sends: list
     recvs: list
+    deferred: bool = False   # True: the data are needed only when the generator yields `Complete`
+
+
+class Complete:
+    """Yielded after a deferred `Exchange`: the received halo rows must be in place before resuming."""
 
 
 class Engine:
@@ -391,20 +396,28 @@ class Engine:
     def step(self, batch: Batch) -> Batch:
         """One forecast step.  With sharding, halo exchanges run as NCCL/RCCL point-to-point groups."""
         gen = self.step_gen(batch)
+        pending = []
         try:
             req = next(gen)
             while True:
-                self._exchange(req)
+                if isinstance(req, Complete):
+                    for work in pending:
+                        work.wait()  # stream-ordered: the current HIP stream waits, not the host
+                    pending = []
+                else:
+                    pending = self._exchange(req)
                 req = gen.send(None)
         except StopIteration as done:
             return done.value
 
-    def _exchange(self, req: Exchange) -> None:
-        """Carry out one halo exchange with torch.distributed point-to-point operations.
+    def _exchange(self, req: Exchange) -> list:
+        """Start one halo exchange with torch.distributed point-to-point operations; returns the works that are
+        still in flight (to be waited for at the matching `Complete`; empty if the exchange was not deferred).
 
         backend "nccl" (= RCCL on ROCm): device tensors go straight over xGMI, grouped into one
-        ncclGroup per exchange; the current HIP stream waits for completion, the host does not.
-        backend "gloo" (tests: several processes sharing one GPU): staged through host memory.
+        ncclGroup per exchange on RCCL's own stream, so kernels launched meanwhile (the interior windows) overlap
+        the transfer; waiting makes the current HIP stream wait, not the host.
+        backend "gloo" (tests: several processes sharing one GPU): staged through host memory, synchronously.
         """
         import torch.distributed as dist
 
@@ -418,11 +431,15 @@ class Engine:
                 work.wait()
             for _, t, h in host_recv:
                 t.copy_(h)
-            return
+            return []
         ops = [dist.P2POp(dist.isend, t, to_global(peer), sh.group) for peer, t in req.sends]
         ops += [dist.P2POp(dist.irecv, t, to_global(peer), sh.group) for peer, t in req.recvs]
-        for work in dist.batch_isend_irecv(ops):
-            work.wait()  # stream-ordered: the current HIP stream waits, not the host
+        works = dist.batch_isend_irecv(ops)
+        if req.deferred:
+            return works
+        for work in works:
+            work.wait()
+        return []
 
     def step_gen(self, batch: Batch):
         """Generator form of the step: yields `Exchange` requests (sharded mode only) and returns the
@@ -780,9 +797,15 @@ class Engine:
         key = (tuple(res), shifted, tuple(rows_s))
         if key not in self._plan_cache:
             p = partition.block_plans(tuple(res), tuple(self.cfg.window_size), shifted, tuple(rows_s))[self.shard.rank]
-            self._plan_cache[key] = dict(
-                tok=self._dev(p.tok), grp=None if p.grp is None else self._dev(p.grp), n_own=p.n_own, n_halo=p.n_halo,
-                recv=dict(p.recv), send={q: self._dev(idx) for q, idx in p.send.items()})
+            d = dict(tok=self._dev(p.tok), grp=None if p.grp is None else self._dev(p.grp), n_own=p.n_own,
+                     n_halo=p.n_halo, recv=dict(p.recv), send={q: self._dev(idx) for q, idx in p.send.items()})
+            # windows that touch no halo row can be attended while the exchange is in flight
+            needs_halo = (p.tok >= p.n_own).any(axis=1)
+            for name, sel in (("interior", ~needs_halo), ("boundary", needs_halo)):
+                d[name] = None
+                if sel.any():
+                    d[name] = (self._dev(p.tok[sel]), None if p.grp is None else self._dev(p.grp[sel]))
+            self._plan_cache[key] = d
         return self._plan_cache[key]
 
     def _backbone(self, x_f, x_b, B, patch_res, rollout_step: int, rows=None):
@@ -824,13 +847,23 @@ class Engine:
                     assert pl["n_own"] == Ls
                     qkv = self.empty(Ls + pl["n_halo"], 3 * dim, dtype=T_)
                     lib.linear(a_in, w_qkv, blk["qkv.b"], qkv[:Ls])
+                    ao = self.empty(M, dim, dtype=T_)
                     if pl["send"] or pl["recv"]:
+                        # halo rows travel while the windows that need none of them are attended
                         sends = [(q, lib.gather_rows(qkv[:Ls], idx, self.empty(idx.numel(), 3 * dim, dtype=T_)))
                                  for q, idx in pl["send"].items()]
                         recvs = [(q, qkv[Ls + off:Ls + off + cnt]) for q, (off, cnt) in pl["recv"].items()]
-                        yield Exchange(sends, recvs)
-                    ao = lib.window_attention(qkv, blk["qkv.b"], self.empty(M, dim, dtype=T_), pl["tok"], pl["grp"],
-                                              B, Ls + pl["n_halo"], dim, heads, L_out=Ls)
+                        yield Exchange(sends, recvs, deferred=True)
+                        if pl["interior"] is not None:
+                            lib.window_attention(qkv, blk["qkv.b"], ao, *pl["interior"], B, Ls + pl["n_halo"], dim, heads,
+                                                 L_out=Ls)
+                        yield Complete()
+                        if pl["boundary"] is not None:
+                            lib.window_attention(qkv, blk["qkv.b"], ao, *pl["boundary"], B, Ls + pl["n_halo"], dim, heads,
+                                                 L_out=Ls)
+                    else:
+                        lib.window_attention(qkv, blk["qkv.b"], ao, pl["tok"], pl["grp"], B, Ls + pl["n_halo"], dim,
+                                             heads, L_out=Ls)
                 del qkv
                 y = lib.linear(ao, w_proj, blk["proj.b"], self.empty(M, dim, dtype=T_))
                 del ao
