@@ -6,6 +6,8 @@
 //   * unpatchify          : head outputs -> (B, V, C, H, W) fields, clamp + Batch.unnormalise fused
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace aurora {
@@ -85,58 +87,78 @@ struct PercArgs {
   int B; int64_t cols_per_b, kv_bstride, kv_lstride; int Lq, Lk, heads;
 };
 
+// A group of HDIM / 4 adjacent lanes owns one (grid column, head): each lane holds 4 of the head's features, so a
+// group reads a key / value row as one contiguous run (16 lanes x 16 B = 256 B for head_dim 64) and the four groups
+// of a wave -- four adjacent heads -- read 1 KiB contiguous per load instruction.  (One thread per (column, head,
+// query) with the whole head in registers reads 16 B per lane at a 256-byte stride: 1.7 TB/s on kv streams that
+// should run at HBM speed.)  The q.k dot products are reduced across the group with DPP adds (mirror, half-mirror,
+// quad reverse, pair swap); the keys of a column are re-read per query out of L1 (Lk * 2 * HDIM * 4 B <= 7 KiB).
+template <int LPG>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(LPG == 4 || LPG == 8 || LPG == 16 || LPG == 32, "lanes per group");
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  if constexpr (LPG == 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (LPG >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror: i <-> 15 - i
+  if constexpr (LPG >= 8) v += dpp(v, std::integral_constant<int, 0x141>{});    // row_half_mirror: i <-> 7 - i
+  v += dpp(v, std::integral_constant<int, 0x1B>{});                              // quad_perm [3,2,1,0]
+  v += dpp(v, std::integral_constant<int, 0xB1>{});                              // quad_perm [1,0,3,2]
+  return v;
+}
+
 template <typename T, int HDIM>
 __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs p) {
+  constexpr int LPG = HDIM / 4;   // lanes per (column, head)
   const int inner = p.heads * HDIM;
   const int64_t n_cols = (int64_t)p.B * p.cols_per_b;
-  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= n_cols * p.heads * p.Lq) return;
-  const int i = (int)(item % p.Lq);
-  const int h = (int)((item / p.Lq) % p.heads);
-  const int64_t col = item / ((int64_t)p.Lq * p.heads);
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPG;
+  const int d0 = (int)(threadIdx.x % LPG) * 4;
+  if (grp >= n_cols * p.heads) return;   // (whole groups leave together)
+  const int h = (int)(grp % p.heads);
+  const int64_t col = grp / p.heads;
   const int b = (int)(col / p.cols_per_b);
   const int64_t l = col - (int64_t)b * p.cols_per_b;
-
-  const T* qp = reinterpret_cast<const T*>(p.q) + (col * p.q_col_stride + i) * inner + h * HDIM;
   const float scale = rsqrtf((float)HDIM);
-  float qv[HDIM], o[HDIM];
+  const T* kv0 = reinterpret_cast<const T*>(p.kv) + (b * p.kv_bstride + l) * (2 * (int64_t)inner) + h * HDIM + d0;
+  const int64_t kv_step = p.kv_lstride * (2 * (int64_t)inner);
+  // Queries are taken four at a time so that a column's keys / values are read once per chunk, not once per query.
+  constexpr int QC = 4;
+  for (int i0 = 0; i0 < p.Lq; i0 += QC) {
+    float qv[QC][4], o[QC][4], mx[QC], sum[QC];
 #pragma unroll
-  for (int d = 0; d < HDIM; d += 4) {
-    float t4[4];
-    load4(qp + d, t4);
-    qv[d] = t4[0] * scale; qv[d + 1] = t4[1] * scale; qv[d + 2] = t4[2] * scale; qv[d + 3] = t4[3] * scale;
-    o[d] = o[d + 1] = o[d + 2] = o[d + 3] = 0.f;
-  }
-  float mx = -INFINITY, sum = 0.f;
-  for (int j = 0; j < p.Lk; ++j) {
-    const T* kp = reinterpret_cast<const T*>(p.kv) + (b * p.kv_bstride + j * p.kv_lstride + l) * (2 * (int64_t)inner) + h * HDIM;
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < HDIM; d += 4) {
-      float t4[4];
-      load4(kp + d, t4);
-      s = fmaf(qv[d], t4[0], s); s = fmaf(qv[d + 1], t4[1], s);
-      s = fmaf(qv[d + 2], t4[2], s); s = fmaf(qv[d + 3], t4[3], s);
+    for (int c = 0; c < QC; ++c) {
+      const int i = i0 + c < p.Lq ? i0 + c : p.Lq - 1;   // (a padded slot repeats the last query; not stored)
+      load4(reinterpret_cast<const T*>(p.q) + (col * p.q_col_stride + i) * inner + h * HDIM + d0, qv[c]);
+      o[c][0] = o[c][1] = o[c][2] = o[c][3] = 0.f;
+      mx[c] = -INFINITY;
+      sum[c] = 0.f;
     }
-    const float nm = fmaxf(mx, s);
-    const float corr = expf(mx - nm), e = expf(s - nm);
-    mx = nm;
-    sum = sum * corr + e;
-    const T* vp = kp + inner;
+    for (int j = 0; j < p.Lk; ++j) {
+      const T* kp = kv0 + j * kv_step;
+      float k4[4], v4[4];
+      load4(kp, k4);
+      load4(kp + inner, v4);
 #pragma unroll
-    for (int d = 0; d < HDIM; d += 4) {
-      float t4[4];
-      load4(vp + d, t4);
-      o[d] = fmaf(e, t4[0], o[d] * corr); o[d + 1] = fmaf(e, t4[1], o[d + 1] * corr);
-      o[d + 2] = fmaf(e, t4[2], o[d + 2] * corr); o[d + 3] = fmaf(e, t4[3], o[d + 3] * corr);
+      for (int c = 0; c < QC; ++c) {
+        float sc = fmaf(qv[c][0], k4[0], fmaf(qv[c][1], k4[1], fmaf(qv[c][2], k4[2], qv[c][3] * k4[3])));
+        sc = group_sum<LPG>(sc) * scale;
+        const float nm = fmaxf(mx[c], sc);
+        const float corr = expf(mx[c] - nm), e = expf(sc - nm);
+        mx[c] = nm;
+        sum[c] = sum[c] * corr + e;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[c][d] = fmaf(e, v4[d], o[c][d] * corr);
+      }
     }
-  }
-  const float inv = 1.0f / sum;
-  T* op = reinterpret_cast<T*>(p.out) + (col * p.Lq + i) * inner + h * HDIM;
 #pragma unroll
-  for (int d = 0; d < HDIM; d += 4) {
-    const float t4[4] = {o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
-    store4(op + d, t4);
+    for (int c = 0; c < QC; ++c) {
+      if (i0 + c < p.Lq) {
+        const float inv = 1.0f / sum[c];
+        const float r4[4] = {o[c][0] * inv, o[c][1] * inv, o[c][2] * inv, o[c][3] * inv};
+        store4(reinterpret_cast<T*>(p.out) + (col * p.Lq + i0 + c) * inner + h * HDIM + d0, r4);
+      }
+    }
   }
 }
 
@@ -270,7 +292,7 @@ extern "C" int aurora_hip_perceiver_attention(const void* q, int64_t q_col_strid
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "perceiver_attention: bad dtype");
   AURORA_CHECK_ARG(Lq > 0 && Lk > 0 && heads > 0 && B > 0 && cols_per_b > 0, "perceiver_attention: empty problem");
   PercArgs p{q, q_col_stride, kv, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads};
-  const int64_t items = (int64_t)B * cols_per_b * heads * Lq;
+  const int64_t items = (int64_t)B * cols_per_b * heads * (head_dim / 4);   // one lane per 4 features of a head
   const dim3 grid(blocks_for(items, 256)), block(256);
 #define AURORA_PERC(TT, HDIM) hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM>), grid, block, 0, as_stream(stream), p)
   if (dtype == AURORA_F32) {

@@ -273,8 +273,9 @@ def merge_ln(x: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, out: torch
              B: int, C: int, H: int, W: int, D: int, eps: float = 1e-5) -> torch.Tensor:
     assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == B * C * H * W * D
     assert out.is_contiguous() and out.numel() == B * C * ((H + 1) // 2) * ((W + 1) // 2) * 4 * D
-    _check(load().aurora_hip_merge_ln(_ptr(x), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, C, H, W, D, eps,
-                                      dtype_code(out.dtype), _stream()))
+    with _Timed("merge_ln", 0.0):
+        _check(load().aurora_hip_merge_ln(_ptr(x), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, C, H, W, D, eps,
+                                          dtype_code(out.dtype), _stream()))
     return out
 
 
@@ -283,8 +284,9 @@ def split_ln(y: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, out: torch
              eps: float = 1e-5) -> torch.Tensor:
     assert y.is_contiguous() and y.numel() == B * C * H * W * 4 * Dq and y.dtype == out.dtype
     assert out.is_contiguous() and out.numel() == B * C * (2 * H - crop_h) * (2 * W - crop_w) * Dq
-    _check(load().aurora_hip_split_ln(_ptr(y), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, C, H, W, Dq,
-                                      crop_h, crop_w, eps, dtype_code(y.dtype), _stream()))
+    with _Timed("split_ln", 0.0):
+        _check(load().aurora_hip_split_ln(_ptr(y), _ptr(ln_w), _ptr(ln_b), _ptr(out), B, C, H, W, Dq,
+                                          crop_h, crop_w, eps, dtype_code(y.dtype), _stream()))
     return out
 
 
@@ -293,8 +295,9 @@ def patchify(desc: list[PatchVar], out: torch.Tensor, k_offset: int, k_total: in
     Kpad = out.shape[1]
     assert out.is_contiguous() and out.shape[0] == n_lvl * B * Hp * Wp
     arr = (PatchVar * len(desc))(*desc)
-    _check(load().aurora_hip_patchify(arr, len(desc), _ptr(out), Kpad, k_offset, k_total, B, T, n_lvl,
-                                      Hp, Wp, P, dtype_code(out.dtype), _stream()))
+    with _Timed("patchify", 0.0):
+        _check(load().aurora_hip_patchify(arr, len(desc), _ptr(out), Kpad, k_offset, k_total, B, T, n_lvl,
+                                          Hp, Wp, P, dtype_code(out.dtype), _stream()))
 
 
 def perceiver_attention(q: torch.Tensor, q_col_stride: int, kv: torch.Tensor, out: torch.Tensor,
@@ -302,9 +305,10 @@ def perceiver_attention(q: torch.Tensor, q_col_stride: int, kv: torch.Tensor, ou
                         heads: int, head_dim: int) -> torch.Tensor:
     assert q.is_contiguous() and kv.is_contiguous() and out.is_contiguous()
     assert q.dtype == kv.dtype == out.dtype
-    _check(load().aurora_hip_perceiver_attention(_ptr(q), q_col_stride, _ptr(kv), _ptr(out), B,
-                                                 cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads,
-                                                 head_dim, dtype_code(q.dtype), _stream()))
+    with _Timed("perceiver_attention", 0.0):
+        _check(load().aurora_hip_perceiver_attention(_ptr(q), q_col_stride, _ptr(kv), _ptr(out), B,
+                                                     cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads,
+                                                     head_dim, dtype_code(q.dtype), _stream()))
     return out
 
 
@@ -314,8 +318,9 @@ def assemble_tokens(surf: torch.Tensor, agg: torch.Tensor, pos_scale: torch.Tens
     for t in (surf, agg, pos_scale, time_emb, out_f32):
         assert t.dtype == torch.float32 and t.is_contiguous()
     code = BF16 if out_t is not None else F32
-    _check(load().aurora_hip_assemble_tokens(_ptr(surf), _ptr(agg), _ptr(pos_scale), _ptr(time_emb),
-                                             _ptr(out_f32), _ptr(out_t), B, Cl, L, D, code, _stream()))
+    with _Timed("assemble_tokens", 0.0):
+        _check(load().aurora_hip_assemble_tokens(_ptr(surf), _ptr(agg), _ptr(pos_scale), _ptr(time_emb),
+                                                 _ptr(out_f32), _ptr(out_t), B, Cl, L, D, code, _stream()))
 
 
 def unpatchify(y: torch.Tensor, desc: list[UnpatchVar], B: int, n_lvl: int, Hp: int, Wp: int,
@@ -323,15 +328,17 @@ def unpatchify(y: torch.Tensor, desc: list[UnpatchVar], B: int, n_lvl: int, Hp: 
     ldy, _ = _rows(y)
     assert y.dtype == torch.float32
     arr = (UnpatchVar * len(desc))(*desc)
-    _check(load().aurora_hip_unpatchify(_ptr(y), ldy, arr, len(desc), B, n_lvl, Hp, Wp, P, _stream()))
+    with _Timed("unpatchify", 0.0):
+        _check(load().aurora_hip_unpatchify(_ptr(y), ldy, arr, len(desc), B, n_lvl, Hp, Wp, P, _stream()))
 
 
 def copy2d(src: torch.Tensor, dst: torch.Tensor, cols: Optional[int] = None) -> None:
     lds_, cs = _rows(src)
     ldd, _ = _rows(dst)
     assert src.dtype == dst.dtype and src.shape[0] == dst.shape[0]
-    _check(load().aurora_hip_copy2d(_ptr(src), lds_, _ptr(dst), ldd, src.shape[0],
-                                    cols if cols is not None else cs, dtype_code(src.dtype), _stream()))
+    with _Timed("copy2d", 0.0):
+        _check(load().aurora_hip_copy2d(_ptr(src), lds_, _ptr(dst), ldd, src.shape[0],
+                                        cols if cols is not None else cs, dtype_code(src.dtype), _stream()))
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
@@ -341,13 +348,15 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> torc
     assert w == wd and src.dtype == dst.dtype and idx.dtype == torch.int32 and idx.is_contiguous()
     assert dst.shape[0] == idx.numel()
     es = src.element_size()
-    _check(load().aurora_hip_gather_rows(_ptr(src), lds_ * es, _ptr(idx), _ptr(dst), ldd * es, idx.numel(), w * es,
-                                         _stream()))
+    with _Timed("gather_rows", 0.0):
+        _check(load().aurora_hip_gather_rows(_ptr(src), lds_ * es, _ptr(idx), _ptr(dst), ldd * es, idx.numel(), w * es,
+                                             _stream()))
     return dst
 
 
 def convert(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
     assert {src.dtype, dst.dtype} == {torch.float32, torch.bfloat16}
-    _check(load().aurora_hip_convert(_ptr(src), _ptr(dst), src.numel(), dtype_code(src.dtype), _stream()))
+    with _Timed("convert", 0.0):
+        _check(load().aurora_hip_convert(_ptr(src), _ptr(dst), src.numel(), dtype_code(src.dtype), _stream()))
     return dst
