@@ -2,6 +2,8 @@
 import sys
 from pathlib import Path
 
+import os
+
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -25,7 +27,11 @@ if len(sys.argv) > 2:  # restrict to the named shapes
 tot_ms = tot_fl = 0.0
 for name, M, N, K, wt in SHAPES:
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dtype)
+    if os.environ.get("GEMM_BENCH_ZERO"):   # power experiment: all-zero operands toggle no datapath bits
+        a.zero_()
     w = ((torch.rand(N, K, device="cuda") * 2 - 1) * K ** -0.5).to(dtype)
+    if os.environ.get("GEMM_BENCH_ZERO"):
+        w.zero_()
     b = torch.rand(N, device="cuda")
     out = torch.empty(M, N, device="cuda", dtype=dtype)
     for _ in range(2):
