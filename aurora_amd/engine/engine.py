@@ -110,6 +110,7 @@ class Engine:
         self.shard: Optional[Shard] = getattr(model, "_shard", None)
         self._plan_cache: dict = {}
         self._time_bufs: dict = {}     # B -> persistent device buffers of the clock-dependent inputs
+        self._pinned: dict = {}        # (shape, dtype) -> ring of pinned staging buffers for `_upload`
         self._capturing = False        # True while a hipGraph of the step is being captured
         self._pack_static()
 
@@ -305,7 +306,9 @@ class Engine:
         Looked up by tensor identity first (a roll-out passes the same lat/lon objects from step
         to step, so no device->host copy happens per step), then by content.
         """
-        ident = (id(lat), id(lon), lat.data_ptr(), lon.data_ptr())
+        # (storage address + shape, not object identity: `Batch.crop` makes a fresh view of the same coordinates
+        # on every call, and a miss costs a device->host copy, i.e. a full synchronisation per step)
+        ident = (lat.data_ptr(), tuple(lat.shape), lon.data_ptr(), tuple(lon.shape))
         hit = self._grid_cache.get("ident")
         if hit is not None and hit[0] == ident:
             return hit[3]
@@ -581,14 +584,29 @@ class Engine:
             self._time_bufs[B] = bufs
         if not self._capturing:
             stamps = [t.timestamp() / 3600 for t in times]
-            bufs["abs_enc"].copy_(torch.from_numpy(encodings.absolute_time(stamps, D)))
+            self._upload(bufs["abs_enc"], encodings.absolute_time(stamps, D))
             if self.cfg.dynamic_vars:
                 vals = np.array([[np.cos(2 * np.pi * t.hour / 24), np.sin(2 * np.pi * t.hour / 24),
                                   np.cos(2 * np.pi * t.weekday() / 7), np.sin(2 * np.pi * t.weekday() / 7),
                                   np.cos(2 * np.pi * t.day / 365.25), np.sin(2 * np.pi * t.day / 365.25)]
                                  for t in times], dtype=np.float64).astype(np.float32)  # (B, 6)
-                bufs["dyn"].copy_(torch.from_numpy(np.ascontiguousarray(vals.T)))
+                self._upload(bufs["dyn"], np.ascontiguousarray(vals.T))
         return bufs
+
+    def _upload(self, dst: torch.Tensor, arr: np.ndarray) -> None:
+        """Host -> device copy that does not stall the host: staged through a small ring of pinned buffers (a
+        pageable `copy_` waits for everything queued before it, i.e. for the whole previous step)."""
+        ring = self._pinned.setdefault((tuple(dst.shape), dst.dtype), {"slots": [], "next": 0})
+        if len(ring["slots"]) < 4:
+            ring["slots"].append((torch.empty(dst.shape, dtype=dst.dtype).pin_memory(), torch.cuda.Event()))
+            slot = ring["slots"][-1]
+        else:
+            slot = ring["slots"][ring["next"] % 4]
+            slot[1].synchronize()          # the copy that used this slot four uploads ago has finished
+        ring["next"] += 1
+        slot[0].copy_(torch.from_numpy(arr).reshape(dst.shape))
+        dst.copy_(slot[0], non_blocking=True)
+        slot[1].record()
 
     # -- encoder ------------------------------------------------------------------------------
     def _var_desc(self, t: torch.Tensor, kind: str, name: str, levels: tuple, transform=0, comb=None) -> lib.PatchVar:
