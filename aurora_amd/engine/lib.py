@@ -146,12 +146,16 @@ def _rows(t: torch.Tensor) -> tuple[int, int]:
 
 # ---- optional per-launch timing (bench.py / tools): HIP events on the launch stream -----------
 _profile: Optional[list] = None
+_profile_only: Optional[set] = None
 
 
-def profile_start() -> None:
-    """Start recording (kernel, algorithmic work, start event, stop event) for every launch."""
-    global _profile
+def profile_start(only: Optional[set] = None) -> None:
+    """Start recording (kernel, algorithmic work, start event, stop event) for every launch, or for the
+    kernels named in `only` (an event pair around a launch keeps it from overlapping its neighbours, so timing
+    every launch of a step costs a few percent of the step)."""
+    global _profile, _profile_only
     _profile = []
+    _profile_only = only
 
 
 def profile_stop() -> dict:
@@ -176,13 +180,14 @@ class _Timed:
         self.name, self.work = name, work
 
     def __enter__(self):
-        if _profile is not None:
+        self.on = _profile is not None and (_profile_only is None or self.name in _profile_only)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def __exit__(self, *exc):
-        if _profile is not None:
+        if self.on:
             self.e1.record()
             _profile.append((self.name, self.work, self.e0, self.e1))
         return False
