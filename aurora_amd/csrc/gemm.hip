@@ -811,6 +811,19 @@ int f32_mode() {
 
 }  // namespace
 
+namespace {
+int device_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    (void)hipGetDevice(&dev);
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+}  // namespace
+
 extern "C" int aurora_hip_set_f32_gemm(int mode) {
   const int prev = f32_mode();
   if (mode == 0 || mode == 1) g_f32_mode = mode;
@@ -837,7 +850,17 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
   // (fp32 in split mode: the kernel choice must not depend on M, or a latitude band of a sharded model
   // would round differently from the same rows of the un-sharded one.)
   const bool split = dtype == AURORA_F32 && f32_mode() == 1;
-  const bool big = (M >= 1024 || split) && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
+  bool big = (M >= 1024 || split) && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
+  if (big && !split) {
+    // Few tiles (a latitude band of a sharded model, the coarse stages): 256 x 256 tiles leave CUs idle or end in a
+    // thin last round, where 128 x 128 tiles (two workgroups per CU, ~0.8 of the big kernel's rate when both are
+    // full) fill the chip.  Compare the fill of the rounds each tiling needs (measured, tools/gemm_bench.py r8.*).
+    const int64_t cus = device_cus();
+    const int64_t nb_big = ((M + BM2 - 1) / BM2) * (N / BN2), nb_small = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const double fill_big = (double)nb_big / (double)(((nb_big + cus - 1) / cus) * cus);
+    const double fill_small = (double)nb_small / (double)(((nb_small + 2 * cus - 1) / (2 * cus)) * 2 * cus);
+    if (0.8 * fill_small > fill_big) big = false;
+  }
   const int bm = big ? BM2 : BM, bn = big ? BN2 : BN, rowb = big ? ROW2 : ROW_BYTES;
   LinearArgs p;
   p.A = (const char*)A; p.lda_b = lda * es;
