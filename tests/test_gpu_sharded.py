@@ -18,13 +18,18 @@ from tests.golden_cases import CASES
 pytestmark = pytest.mark.gpu
 
 
-def run_virtual_ranks(model, batch, world):
-    """Advance `world` sharded step generators until all finish; returns the per-rank BandBatches."""
+def make_engines(model, world):
     engines = []
     for r in range(world):
         model._shard = Shard(r, world, None, gather_output=False)
         engines.append(Engine(model))
     model._shard = None
+    return engines
+
+
+def run_virtual_ranks(model, batch, world, engines=None):
+    """Advance `world` sharded step generators until all finish; returns the per-rank BandBatches."""
+    engines = engines or make_engines(model, world)
     gens = [e.step_gen(batch if not isinstance(batch, list) else batch[r]) for r, e in enumerate(engines)]
     mailbox = defaultdict(deque)           # (src, dst) -> tensors in posting order
     waiting, done = {}, {}
