@@ -28,6 +28,7 @@ SHAPES = [  # (name, M, N, K, weight in the step)
 dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
 if len(sys.argv) > 2:  # restrict to the named shapes
     SHAPES = [s_ for s_ in SHAPES if s_[0] in sys.argv[2].split(",")]
+ACT = int(os.environ.get("GEMM_BENCH_ACT", "0"))   # 1 = GELU epilogue
 tot_ms = tot_fl = 0.0
 for name, M, N, K, wt in SHAPES:
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dtype)
@@ -39,13 +40,13 @@ for name, M, N, K, wt in SHAPES:
     b = torch.rand(N, device="cuda")
     out = torch.empty(M, N, device="cuda", dtype=dtype)
     for _ in range(2):
-        lib.linear(a, w, b, out)
+        lib.linear(a, w, b, out, act=ACT)
     torch.cuda.synchronize()
     reps = 5
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        lib.linear(a, w, b, out)
+        lib.linear(a, w, b, out, act=ACT)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps

@@ -2,6 +2,8 @@
 import sys
 from pathlib import Path
 
+import os
+
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -14,12 +16,12 @@ for K in (64, 128, 256, 512, 1024, 2048, 4096):
     w = ((torch.rand(N, K, device="cuda") * 2 - 1) * K ** -0.5).to(dtype)
     out = torch.empty(M, N, device="cuda", dtype=dtype)
     for _ in range(2):
-        lib.linear(a, w, None, out)
+        lib.linear(a, w, None, out, act=int(os.environ.get("KSWEEP_ACT", "0")))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        lib.linear(a, w, None, out)
+        lib.linear(a, w, None, out, act=int(os.environ.get("KSWEEP_ACT", "0")))
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
