@@ -86,6 +86,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs p) {
   }
 }
 
+// fp32 rows: 16-byte pieces (4 features) per lane and chunk, lanes on consecutive pieces -- every load / store
+// instruction of a wave covers 1 KiB contiguous.  (The generic kernel above gives a lane 8 consecutive features,
+// 32 bytes for fp32, so each of its two 16-byte accesses touches every line of the row only half: measured
+// 3.0 TB/s on the 842400 x 512 decoder LayerNorms against 6.4 TB/s for the bf16-input ones.)
+template <int NC>   // chunks of 256 features
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int n_pieces = p.D >> 2;
+  const float* yr = reinterpret_cast<const float*>(p.y) + row * p.ldy;
+  float v[NC][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+    if (lane + 64 * i < n_pieces) {
+      load4(yr + (lane + 64 * i) * 4, v[i]);
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  const float inv_d = 1.0f / p.D;
+  const float mean = wave_sum(s) * inv_d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+    if (lane + 64 * i < n_pieces) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[i][j] - mean;
+        q = fmaf(d, d, q);
+      }
+    }
+  const float rstd = rsqrtf(wave_sum(q) * inv_d + p.eps);
+  const float* rr = nullptr;
+  if (p.res) rr = p.res + (p.res_mod > 0 ? row % p.res_mod : row) * p.ldr;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int e = (lane + 64 * i) * 4;
+    if (lane + 64 * i < n_pieces) {
+      float gn[4], sh[4], o[4];
+      if (p.gain) load4(p.gain + e, gn);
+      if (p.shift) load4(p.shift + e, sh);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = (v[i][j] - mean) * rstd;
+        if (p.gain) t *= gn[j];
+        if (p.shift) t += sh[j];
+        o[j] = t;
+      }
+      if (rr) {
+        float r4[4];
+        load4(rr + e, r4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += r4[j];
+      }
+      if (p.out_f32) store4(p.out_f32 + row * p.ldo + e, o);
+      if (p.out_t) store4(reinterpret_cast<float*>(p.out_t) + row * p.ldt + e, o);
+    }
+  }
+}
+
 struct MergeArgs {
   const float* x; const float* w; const float* b; void* out;
   int B, C, H, W, D, H2, W2; float eps;
@@ -203,10 +263,16 @@ extern "C" int aurora_hip_layernorm(const void* y, int64_t ldy, const float* gai
   AURORA_CHECK_ARG(out_f32 || out_t, "layernorm: no output");
   if (M <= 0) return AURORA_OK;
   LnArgs p{y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps};
-  if (dtype == AURORA_F32)
-    AURORA_DISPATCH_ROW(layernorm_kernel, float, D, dim3(row_blocks(M)), dim3(256), 0, as_stream(stream), p);
-  else
+  if (dtype == AURORA_F32) {
+    const dim3 grid(row_blocks(M)), block(256);
+    if (D <= 256) hipLaunchKernelGGL(layernorm_f32_kernel<1>, grid, block, 0, as_stream(stream), p);
+    else if (D <= 512) hipLaunchKernelGGL(layernorm_f32_kernel<2>, grid, block, 0, as_stream(stream), p);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_f32_kernel<4>, grid, block, 0, as_stream(stream), p);
+    else if (D <= 2048) hipLaunchKernelGGL(layernorm_f32_kernel<8>, grid, block, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(layernorm_f32_kernel<16>, grid, block, 0, as_stream(stream), p);
+  } else {
     AURORA_DISPATCH_ROW(layernorm_kernel, bf16_t, D, dim3(row_blocks(M)), dim3(256), 0, as_stream(stream), p);
+  }
   return check_launch("layernorm");
 }
 
