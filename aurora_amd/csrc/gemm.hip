@@ -673,6 +673,42 @@ __device__ __forceinline__ f32x4 mma_bf16(u32x4 a, u32x4 b, f32x4 c) {
                                                  c, 0, 0, 0);
 }
 
+// ---- second variant: two fp16 terms ----
+// With round-to-nearest, a = a_h + a_l where a_h = fp16(a) and a_l = fp16(a - a_h) reproduces a to 2^-24 |a| (the
+// remainder is exact in fp32, has <= 14 significant bits and loses at most its last three to the 11-bit fp16
+// significand), so  a.b = a_h b_h + a_h b_l + a_l b_h + O(2^-24 |a||b|)  needs THREE MFMAs (fp16 x fp16 products are
+// exact in the fp32 accumulator) and 5 VALU operations per operand pair instead of six MFMAs and 9.  The price is
+// fp16's range: a_h overflows at |a| >= 65520, and a_l is a subnormal for |a| < 0.25, i.e. carries an ABSOLUTE error
+// of up to 3e-8.  The weight operand is therefore scaled by 2^6 on the fly (nn.Linear weights are O(1e-2); the
+// accumulators are scaled back exactly in the epilogue) and the variant is only used where the caller vouches for
+// activations that are bounded by construction (aurora_hip_set_f32_gemm(2): LayerNorm outputs and their GELU'd linears).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+struct Split2 { u32x4 h, l; };
+
+__device__ __forceinline__ void split_pair_f16(float a0, float a1, uint32_t& h, uint32_t& l) {
+  const f32x2_t v = {a0, a1};
+  const f16x2_t hh = __builtin_convertvector(v, f16x2_t);             // v_cvt_pk_f16_f32 (round to nearest even)
+  const f32x2_t r = v - __builtin_convertvector(hh, f32x2_t);         // exact
+  h = __builtin_bit_cast(uint32_t, hh);
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+}
+template <bool SCALE>
+__device__ __forceinline__ Split2 split8_f16(u32x4 a, u32x4 b) {
+  constexpr float S = SCALE ? 64.0f : 1.0f;
+  uint32_t h[4], l[4];
+  split_pair_f16(__uint_as_float(a.x) * S, __uint_as_float(a.y) * S, h[0], l[0]);
+  split_pair_f16(__uint_as_float(a.z) * S, __uint_as_float(a.w) * S, h[1], l[1]);
+  split_pair_f16(__uint_as_float(b.x) * S, __uint_as_float(b.y) * S, h[2], l[2]);
+  split_pair_f16(__uint_as_float(b.z) * S, __uint_as_float(b.w) * S, h[3], l[3]);
+  return Split2{u32x4{h[0], h[1], h[2], h[3]}, u32x4{l[0], l[1], l[2], l[3]}};
+}
+__device__ __forceinline__ f32x4 mma_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+template <int TERMS>   // 3: three bf16 terms, six MFMAs;  2: two fp16 terms, three MFMAs
 __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const LinearArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -746,32 +782,56 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
   for (int j = 0; j < np; ++j) {
     const char* bufa = smem + ((2 * j) & (NSTAGE2 - 1)) * STAGE2;
     const char* bufb = smem + ((2 * j + 1) & (NSTAGE2 - 1)) * STAGE2;
-    Split3 w[4];
+    if constexpr (TERMS == 3) {
+      Split3 w[4];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
-      w[f] = split8(*reinterpret_cast<const u32x4*>(bufa + off_w[f]), *reinterpret_cast<const u32x4*>(bufb + off_w[f]));
-    u32x4 ra = *reinterpret_cast<const u32x4*>(bufa + off_x[0]);
-    u32x4 rb = *reinterpret_cast<const u32x4*>(bufb + off_x[0]);
+      for (int f = 0; f < 4; ++f)
+        w[f] = split8(*reinterpret_cast<const u32x4*>(bufa + off_w[f]), *reinterpret_cast<const u32x4*>(bufb + off_w[f]));
+      u32x4 ra = *reinterpret_cast<const u32x4*>(bufa + off_x[0]);
+      u32x4 rb = *reinterpret_cast<const u32x4*>(bufb + off_x[0]);
 #pragma unroll
-    for (int fm = 0; fm < 8; ++fm) {
-      const Split3 x = split8(ra, rb);
-      if (fm + 1 < 8) {
-        ra = *reinterpret_cast<const u32x4*>(bufa + off_x[fm + 1]);
-        rb = *reinterpret_cast<const u32x4*>(bufb + off_x[fm + 1]);
+      for (int fm = 0; fm < 8; ++fm) {
+        const Split3 x = split8(ra, rb);
+        if (fm + 1 < 8) {
+          ra = *reinterpret_cast<const u32x4*>(bufa + off_x[fm + 1]);
+          rb = *reinterpret_cast<const u32x4*>(bufb + off_x[fm + 1]);
+        }
+        // smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].l, x.h, acc[fn][fm]);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.l, acc[fn][fm]);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].m, x.m, acc[fn][fm]);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].m, x.h, acc[fn][fm]);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.m, acc[fn][fm]);
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.h, acc[fn][fm]);
       }
-      // smallest terms first; consecutive MFMAs go to different accumulators
+    } else {
+      Split2 w[4];
 #pragma unroll
-      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].l, x.h, acc[fn][fm]);
+      for (int f = 0; f < 4; ++f)
+        w[f] = split8_f16<true>(*reinterpret_cast<const u32x4*>(bufa + off_w[f]),
+                                *reinterpret_cast<const u32x4*>(bufb + off_w[f]));
+      u32x4 ra = *reinterpret_cast<const u32x4*>(bufa + off_x[0]);
+      u32x4 rb = *reinterpret_cast<const u32x4*>(bufb + off_x[0]);
 #pragma unroll
-      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.l, acc[fn][fm]);
+      for (int fm = 0; fm < 8; ++fm) {
+        const Split2 x = split8_f16<false>(ra, rb);
+        if (fm + 1 < 8) {
+          ra = *reinterpret_cast<const u32x4*>(bufa + off_x[fm + 1]);
+          rb = *reinterpret_cast<const u32x4*>(bufb + off_x[fm + 1]);
+        }
 #pragma unroll
-      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].m, x.m, acc[fn][fm]);
+        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_f16(w[fn].l, x.h, acc[fn][fm]);
 #pragma unroll
-      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].m, x.h, acc[fn][fm]);
+        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_f16(w[fn].h, x.l, acc[fn][fm]);
 #pragma unroll
-      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.m, acc[fn][fm]);
-#pragma unroll
-      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.h, acc[fn][fm]);
+        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_f16(w[fn].h, x.h, acc[fn][fm]);
+      }
     }
     if (j + 1 < np) {
       // RAW: my pieces of pair j+1 (issued a whole pair ago) have landed; WAR: everyone has read pair j.
@@ -783,6 +843,12 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
         stage(2 * j + 5);
       }
     }
+  }
+  if constexpr (TERMS == 2) {   // undo the 2^6 weight scale (exact)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[a][b] *= 0.015625f;
   }
   if (p.C2 == nullptr && p.vec_store) {   // (uniform)
     __syncthreads();   // every wave is done with the ring
@@ -799,12 +865,12 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
 using namespace aurora;
 
 namespace {
-// 0: native fp32 MFMA (v_mfma_f32_16x16x4_f32); 1: 3 x bf16 operand splitting (default).
+// 0: native fp32 MFMA (v_mfma_f32_16x16x4_f32); 1: 3 x bf16 operand splitting (default); 2: 2 x fp16 splitting.
 int g_f32_mode = -1;
 int f32_mode() {
   if (g_f32_mode < 0) {
     const char* e = getenv("AURORA_F32_GEMM");
-    g_f32_mode = (e && e[0] == 'n') ? 0 : 1;   // AURORA_F32_GEMM=native
+    g_f32_mode = !e ? 1 : (e[0] == 'n' || e[0] == '0') ? 0 : (e[0] == 'f' || e[0] == '2') ? 2 : 1;   // native | bf16 | f16
   }
   return g_f32_mode;
 }
@@ -826,7 +892,7 @@ int device_cus() {
 
 extern "C" int aurora_hip_set_f32_gemm(int mode) {
   const int prev = f32_mode();
-  if (mode == 0 || mode == 1) g_f32_mode = mode;
+  if (mode >= 0 && mode <= 2) g_f32_mode = mode;
   return prev;
 }
 
@@ -849,7 +915,7 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
   // Big backbone shapes take the 256 x 256 ring kernel; everything else the 128 x 128 one.
   // (fp32 in split mode: the kernel choice must not depend on M, or a latitude band of a sharded model
   // would round differently from the same rows of the un-sharded one.)
-  const bool split = dtype == AURORA_F32 && f32_mode() == 1;
+  const bool split = dtype == AURORA_F32 && f32_mode() >= 1;
   bool big = (M >= 1024 || split) && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
   if (big && !split) {
     // Few tiles (a latitude band of a sharded model, the coarse stages): 256 x 256 tiles leave CUs idle or end in a
@@ -884,12 +950,15 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
     (void)hipFuncSetAttribute((const void*)linear_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<float, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     attr_done = true;
   }
   if (big) {
-    if (split)
-      hipLaunchKernelGGL(linear_kernel_256_f32x3, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    if (split && f32_mode() == 2)
+      hipLaunchKernelGGL(linear_kernel_256_f32x3<2>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    else if (split)
+      hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (dtype == AURORA_F32)
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else

@@ -794,7 +794,7 @@ class Engine:
                                           kv_lstride, Lq, Lk, heads, hd)
             del kv
             D = ly["to_out"].shape[0]
-            o = self._linear_new(att, ly["to_out"], None, D)
+            o = self._linear_new(att, ly["to_out"], None, D)   # (`att` is as unbounded as the tokens: 3 x bf16 split)
             del att
             lat1 = self.empty(n_rows, D)
             if i == 0:
@@ -802,8 +802,9 @@ class Engine:
             else:
                 lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], res=lat, out_f32=lat1, eps=eps)
             del o
-            hid = self._linear_new(lat1, ly["fc1_w"], ly["fc1_b"], ly["fc1_w"].shape[0], act=lib.ACT_GELU)
-            y = self._linear_new(hid, ly["fc2_w"], ly["fc2_b"], D)
+            with lib.bounded_activations():    # fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU
+                hid = self._linear_new(lat1, ly["fc1_w"], ly["fc1_b"], ly["fc1_w"].shape[0], act=lib.ACT_GELU)
+                y = self._linear_new(hid, ly["fc2_w"], ly["fc2_b"], D)
             del hid
             lib.layernorm(y, ly["ln2_w"], ly["ln2_b"], res=lat1, out_f32=y, eps=eps)
             lat = y

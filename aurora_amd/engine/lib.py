@@ -195,8 +195,26 @@ class _Timed:
 
 # ---- wrappers ------------------------------------------------------------------------------
 def set_f32_gemm(mode: int) -> int:
-    """0 = native fp32 MFMA, 1 = exact 3 x bf16 operand splitting (default); returns the previous mode."""
+    """0 = native fp32 MFMA, 1 = exact 3 x bf16 operand splitting (default), 2 = 2 x fp16 splitting (bounded
+    activations only); returns the previous mode."""
     return load().aurora_hip_set_f32_gemm(mode)
+
+
+class bounded_activations:
+    """`with bounded_activations():` -- the fp32 linears issued inside may use the 2 x fp16 operand split (three
+    MFMAs instead of six, the same 2^-24 operand accuracy): the caller vouches that their activation operand is
+    bounded by construction -- a LayerNorm output or the GELU of a linear of one -- i.e. far inside fp16's range
+    (|x| < 65504) whatever the model's inputs are.  Honours an explicit
+    native / bf16 choice made through AURORA_F32_GEMM or `set_f32_gemm(0)`."""
+
+    def __enter__(self):
+        self.prev = set_f32_gemm(-1)
+        if self.prev == 1 and os.environ.get("AURORA_F32_GEMM") is None:
+            set_f32_gemm(2)
+
+    def __exit__(self, *exc):
+        set_f32_gemm(self.prev)
+        return False
 
 
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,

@@ -53,12 +53,18 @@ int aurora_hip_linear(const void* A, int64_t lda, const void* W, int64_t ldw, co
                       const float* residual, int64_t ldr,
                       int64_t M, int N, int K, int dtype, int act, void* stream);
 
-/* How large fp32 linears (M >= 1024, N % 256 == 0) are multiplied.  1 (default): every fp32 operand is
- * split exactly into three bf16 terms and six bf16 MFMAs per K-slab reproduce the fp32 product to
- * ~1e-7 relative (fp32-grade, 2.7x the fp32 MFMA rate).  0: native v_mfma_f32_16x16x4_f32 FMA chains
- * (also selected by the environment variable AURORA_F32_GEMM=native).  Returns the previous mode;
- * any other argument only queries.  The reference's counterpart is the fp32 F.linear outside
- * autocast (encoder.py / decoder.py, aurora.py:322-349). */
+/* How large fp32 linears (N % 256 == 0) are multiplied.
+ *   1 (default): every fp32 operand is split exactly into three bf16 terms and six bf16 MFMAs per K-slab
+ *      reproduce the fp32 product to ~1e-7 relative (fp32-grade, no range restriction, 16/6 of the fp32 MFMA rate).
+ *   2: two fp16 terms (round-to-nearest: a_h + a_l = a to 2^-24 |a|), three fp16 MFMAs, the weight operand scaled
+ *      by 2^6 and the result scaled back exactly.  Same accuracy, but inside fp16's range only: activations must
+ *      satisfy |x| < 65504 (|x| < 0.25 carries an absolute error of up to 3e-8), weights |w| < 1000.  Meant to be
+ *      switched on around linears whose input is bounded by construction (a LayerNorm output, the GELU of a
+ *      linear of one), whatever the model inputs are.
+ *   0: native v_mfma_f32_16x16x4_f32 FMA chains.
+ * The environment variable AURORA_F32_GEMM=native|bf16|f16 sets the initial mode.  Returns the previous mode; any
+ * other argument only queries.  The reference's counterpart is the fp32 F.linear outside autocast
+ * (encoder.py / decoder.py, aurora.py:322-349). */
 int aurora_hip_set_f32_gemm(int mode);
 
 /* ---- 3D shifted-window attention core ------------------------------------------------------

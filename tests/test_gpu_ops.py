@@ -74,7 +74,7 @@ def test_linear_fp32_by_bf16_splitting_is_fp32_grade(M, N, K):
     err = {}
     prev = L.set_f32_gemm(-1)
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             L.set_f32_gemm(mode)
             out = torch.empty((M, N), device=DEV)
             L.linear(a.to(DEV), w.to(DEV), None, out)
@@ -82,9 +82,13 @@ def test_linear_fp32_by_bf16_splitting_is_fp32_grade(M, N, K):
             err[mode] = ((out.double().cpu() - ref).abs() / scale).max().item()
     finally:
         L.set_f32_gemm(prev)
-    print(f"fp32 linear {M}x{N}x{K}: native MFMA err {err[0]:.2e}, 3xbf16 split err {err[1]:.2e}")
+    print(f"fp32 linear {M}x{N}x{K}: native MFMA err {err[0]:.2e}, 3xbf16 split err {err[1]:.2e}, "
+          f"2xfp16 split err {err[2]:.2e}")
     assert err[0] < 2e-6, err
     assert err[1] < 2e-6 and err[1] < 2 * err[0] + 1e-7, err
+    # two fp16 terms: as accurate, except that activations below 0.25 carry an ABSOLUTE error of up to 3e-8 (fp16
+    # subnormal remainders) -- visible here only for K = 32, where a few tiny elements can dominate the sum
+    assert err[2] < (4e-6 if K < 64 else 2e-6) and (K < 64 or err[2] < 2 * err[0] + 1e-7), err
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (130, 64, 64), (1000, 1536, 512), (129, 80, 2048),
