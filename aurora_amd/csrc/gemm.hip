@@ -1,5 +1,13 @@
 // Dense linear layers on the gfx950 matrix cores:  C = act(A . W^T + bias) (+ residual).
 //
+// Kernels in this file (dispatch: aurora_hip_linear at the end):
+//   linear_kernel<T>            128 x 128 tile, two workgroups per CU -- small / ragged shapes, few-tile shapes
+//   linear_kernel_256<T,4,4>    256 x 256 tile, 4-stage LDS ring     -- the backbone linears (bf16) and native-fp32 mode
+//   linear_kernel_256_f32x3<3>  fp32 by three bf16 terms (6 MFMAs)   -- fp32 linears, any input range
+//   linear_kernel_256_f32x3<2>  fp32 by two fp16 terms (3 MFMAs)     -- fp32 linears with inputs bounded by construction
+//   epilogue_256*               bias / activation / residual; single-dtype results leave as whole rows via LDS
+// The description below is the 128 x 128 kernel; the others document their differences in place.
+//
 // One kernel template serves bf16 (v_mfma_f32_16x16x32_bf16) and fp32
 // (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains) because both are tiled in BYTES: a K-tile
 // is 128 bytes of every operand row (64 bf16 / 32 fp32), staged by 16-byte LDS-DMA pieces
