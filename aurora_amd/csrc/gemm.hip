@@ -56,6 +56,7 @@ struct LinearArgs {
   int64_t M; int N; int k_tiles; int act;
   int tiles_n; int64_t n_blocks;
   int vec_store;                  // 1: every C/C2/res row piece is 16-byte aligned
+  const float* guard; float guard_limit;   // f32 split kernels (guarded launch): two fp16 terms iff *guard < guard_limit
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -719,6 +720,10 @@ __device__ __forceinline__ f32x4 mma_f16(u32x4 a, u32x4 b, f32x4 c) {
 template <int TERMS>   // 3: three bf16 terms, six MFMAs;  2: two fp16 terms, three MFMAs
 __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const LinearArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Guarded launch: the host has launched BOTH variants; the word the caller left in device memory (max |activation|
+  // or a bound of it) decides which one does the work -- two fp16 terms inside the safe range, three bf16 terms
+  // otherwise -- and the other one retires at once.  Uniform: every workgroup reads the same word.
+  if (p.guard != nullptr && (*p.guard < p.guard_limit) != (TERMS == 2)) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -787,10 +792,8 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  for (int j = 0; j < np; ++j) {
-    const char* bufa = smem + ((2 * j) & (NSTAGE2 - 1)) * STAGE2;
-    const char* bufb = smem + ((2 * j + 1) & (NSTAGE2 - 1)) * STAGE2;
-    if constexpr (TERMS == 3) {
+  constexpr bool use_two = TERMS == 2;
+  auto pair3 = [&](const char* bufa, const char* bufb) {
       Split3 w[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f)
@@ -818,7 +821,8 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_bf16(w[fn].h, x.h, acc[fn][fm]);
       }
-    } else {
+  };
+  auto pair2 = [&](const char* bufa, const char* bufb) {
       Split2 w[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f)
@@ -840,7 +844,12 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_f16(w[fn].h, x.h, acc[fn][fm]);
       }
-    }
+  };
+  for (int j = 0; j < np; ++j) {
+    const char* bufa = smem + ((2 * j) & (NSTAGE2 - 1)) * STAGE2;
+    const char* bufb = smem + ((2 * j + 1) & (NSTAGE2 - 1)) * STAGE2;
+    if constexpr (TERMS == 3) pair3(bufa, bufb);
+    else pair2(bufa, bufb);
     if (j + 1 < np) {
       // RAW: my pieces of pair j+1 (issued a whole pair ago) have landed; WAR: everyone has read pair j.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -852,7 +861,7 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
       }
     }
   }
-  if constexpr (TERMS == 2) {   // undo the 2^6 weight scale (exact)
+  if constexpr (use_two) {   // undo the 2^6 weight scale (exact)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -897,6 +906,17 @@ int device_cus() {
   return n;
 }
 }  // namespace
+
+namespace {
+const float* g_guard = nullptr;
+float g_guard_limit = 0.f;
+}  // namespace
+
+extern "C" int aurora_hip_set_f32_guard(const float* device_absmax, float limit) {
+  g_guard = device_absmax;
+  g_guard_limit = limit;
+  return AURORA_OK;
+}
 
 extern "C" int aurora_hip_set_f32_gemm(int mode) {
   const int prev = f32_mode();
@@ -949,6 +969,8 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
   if (C2) vec = vec && ((uintptr_t)C2 % 16) == 0 && (ldc2 * es2) % 16 == 0;
   if (residual) vec = vec && ((uintptr_t)residual % 16) == 0 && (ldr * 4) % 16 == 0;
   p.vec_store = vec ? 1 : 0;
+  p.guard = (split && f32_mode() == 2) ? g_guard : nullptr;
+  p.guard_limit = g_guard_limit;
   AURORA_CHECK_ARG(p.n_blocks < (int64_t)1 << 31, "linear: too many tiles");
 
   dim3 grid((unsigned)p.n_blocks);
@@ -963,7 +985,10 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
     attr_done = true;
   }
   if (big) {
-    if (split && f32_mode() == 2)
+    if (split && f32_mode() == 2 && g_guard != nullptr) {   // both variants; the device word picks one
+      hipLaunchKernelGGL(linear_kernel_256_f32x3<2>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+      hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    } else if (split && f32_mode() == 2)
       hipLaunchKernelGGL(linear_kernel_256_f32x3<2>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (split)
       hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);

@@ -72,6 +72,33 @@ using namespace aurora;
 extern "C" const char* aurora_hip_last_error(void) { return g_err; }
 extern "C" int aurora_hip_version(void) { return 1; }
 
+namespace aurora {
+namespace {
+// max |x| over a contiguous fp32 array: 16-byte loads, wave reduction, one atomic per wave (non-negative floats order
+// like their bit patterns).  NaN compares false everywhere and is ignored; +-inf wins.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, float* out) {
+  float m = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+}  // namespace
+}  // namespace aurora
+
+extern "C" int aurora_hip_absmax(const float* x, int64_t n, float* out, void* stream) {
+  AURORA_CHECK_ARG(x != nullptr && out != nullptr && n > 0 && (uintptr_t)x % 16 == 0, "absmax: bad arguments");
+  if (hipMemsetAsync(out, 0, sizeof(float), as_stream(stream)) != hipSuccess) return AURORA_E_LAUNCH;
+  const int64_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 + 1 : 2048);
+  hipLaunchKernelGGL(aurora::absmax_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n4, n, out);
+  return check_launch("absmax");
+}
+
 extern "C" int aurora_hip_convert(const void* src, void* dst, int64_t n, int src_dtype, void* stream) {
   AURORA_CHECK_ARG(src_dtype == AURORA_F32 || src_dtype == AURORA_BF16, "convert: bad dtype");
   if (n <= 0) return AURORA_OK;

@@ -62,6 +62,9 @@ class Shard:
     gather_output: bool = True    # True: forward() returns the full fields on every rank
 
 
+_F16_SAFE = 16384.0   # activations below this may take the two-term fp16 operand split (fp16 overflows at 65504)
+
+
 @dataclasses.dataclass
 class Exchange:
     """One halo exchange: tensors to send to / receive from peer ranks (contiguous, on the device)."""
@@ -227,6 +230,8 @@ class Engine:
                           "ln_q.w": self._p(f"{p}.0.ln_q.weight"), "ln_q.b": self._p(f"{p}.0.ln_q.bias")})
             d["inner"] = d["to_q"].shape[0]
             d["head_dim"] = d["inner"] // heads
+            # largest L1 row norm of the value projection: |v| <= v_l1 * max |context| (pack time, one sync)
+            d["v_l1"] = max(float(d["to_kv"][d["inner"]:].abs().sum(dim=1).max().item()), 1e-6)
             layers.append(d)
         return layers
 
@@ -778,9 +783,13 @@ class Engine:
         """
         lat = None
         n_rows = B * cols * Lq
+        # The context is as unbounded as the model inputs (raw `randn` fields reach 4e6 here), so the linears that
+        # read it, or averages of its value projection, pick their operand split on the device from max |ctx|.
+        ctx_max = lib.absmax(ctx)
         for i, ly in enumerate(layers):
             inner, hd = ly["inner"], ly["head_dim"]
-            kv = self._linear_new(ctx, ly["to_kv"], None, 2 * inner)
+            with lib.bounded_activations(guard=(ctx_max, _F16_SAFE)):
+                kv = self._linear_new(ctx, ly["to_kv"], None, 2 * inner)
             if "ln_k.w" in ly:  # LayerNorm over the K half, in place (perceiver.py:144-147)
                 lib.layernorm(kv, ly["ln_k.w"], ly["ln_k.b"], out_f32=kv, d=inner)
             if i == 0:
@@ -794,7 +803,9 @@ class Engine:
                                           kv_lstride, Lq, Lk, heads, hd)
             del kv
             D = ly["to_out"].shape[0]
-            o = self._linear_new(att, ly["to_out"], None, D)   # (`att` is as unbounded as the tokens: 3 x bf16 split)
+            # |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
+            with lib.bounded_activations(guard=(ctx_max, _F16_SAFE / ly["v_l1"])):
+                o = self._linear_new(att, ly["to_out"], None, D)
             del att
             lat1 = self.empty(n_rows, D)
             if i == 0:

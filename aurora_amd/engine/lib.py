@@ -50,6 +50,8 @@ _SIGNATURES = {
     "aurora_hip_version": (c_int, []),
     "aurora_hip_last_error": (ctypes.c_char_p, []),
     "aurora_hip_set_f32_gemm": (c_int, [c_int]),
+    "aurora_hip_set_f32_guard": (c_int, [c_void_p, ctypes.c_float]),
+    "aurora_hip_absmax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "aurora_hip_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                   c_int, c_void_p]),
@@ -200,19 +202,37 @@ def set_f32_gemm(mode: int) -> int:
     return load().aurora_hip_set_f32_gemm(mode)
 
 
+def absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """max |x| of a contiguous fp32 tensor into a one-element device tensor (no host synchronisation)."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=x.device) if out is None else out
+    with _Timed("absmax", 0.0):
+        _check(load().aurora_hip_absmax(_ptr(x), x.numel(), _ptr(out), _stream()))
+    return out
+
+
 class bounded_activations:
     """`with bounded_activations():` -- the fp32 linears issued inside may use the 2 x fp16 operand split (three
-    MFMAs instead of six, the same 2^-24 operand accuracy): the caller vouches that their activation operand is
-    bounded by construction -- a LayerNorm output or the GELU of a linear of one -- i.e. far inside fp16's range
-    (|x| < 65504) whatever the model's inputs are.  Honours an explicit
-    native / bf16 choice made through AURORA_F32_GEMM or `set_f32_gemm(0)`."""
+    MFMAs instead of six, the same 2^-24 operand accuracy).  Without arguments the caller vouches that their
+    activation operand is bounded by construction -- a LayerNorm output or the GELU of a linear of one -- i.e. far
+    inside fp16's range (|x| < 65504) whatever the model's inputs are.  With `guard=(amax, limit)` the decision is
+    taken on the device, per launch: fp16 terms iff `amax[0] < limit` (`amax` from `absmax`, or a bound derived from
+    it), three bf16 terms otherwise.  Honours an explicit native / bf16 choice made through AURORA_F32_GEMM or
+    `set_f32_gemm(0)`."""
+
+    def __init__(self, guard=None):
+        self.guard = guard
 
     def __enter__(self):
         self.prev = set_f32_gemm(-1)
         if self.prev == 1 and os.environ.get("AURORA_F32_GEMM") is None:
             set_f32_gemm(2)
+            if self.guard is not None:
+                load().aurora_hip_set_f32_guard(_ptr(self.guard[0]), float(self.guard[1]))
 
     def __exit__(self, *exc):
+        if self.guard is not None:
+            load().aurora_hip_set_f32_guard(None, 0.0)
         set_f32_gemm(self.prev)
         return False
 

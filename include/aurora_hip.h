@@ -67,6 +67,15 @@ int aurora_hip_linear(const void* A, int64_t lda, const void* W, int64_t ldw, co
  * (encoder.py / decoder.py, aurora.py:322-349). */
 int aurora_hip_set_f32_gemm(int mode);
 
+/* Range guard for mode 2: while `device_absmax` is non-null, large fp32 linears issued in mode 2 read that device word
+ * at run time and use the two-term fp16 split only if *device_absmax < limit (else the three-term bf16 split): the
+ * caller leaves max |activation| -- or an upper bound of it, scaled into `limit` -- there, e.g. with
+ * aurora_hip_absmax, without any host synchronisation.  NULL removes the guard. */
+int aurora_hip_set_f32_guard(const float* device_absmax, float limit);
+
+/* out[0] = max |x[i]| over n contiguous fp32 values (x 16-byte aligned); NaNs are ignored. */
+int aurora_hip_absmax(const float* x, int64_t n, float* out, void* stream);
+
 /* ---- 3D shifted-window attention core ------------------------------------------------------
  * For every window w and head h: O = softmax(Q K^T / sqrt(hd) + mask) V over the window's
  * `win_tokens` (<= 144) tokens.  qkv: [B][L][3*D] with columns q | k | v, each head-major

@@ -91,6 +91,27 @@ def test_linear_fp32_by_bf16_splitting_is_fp32_grade(M, N, K):
     assert err[2] < (4e-6 if K < 64 else 2e-6) and (K < 64 or err[2] < 2 * err[0] + 1e-7), err
 
 
+@pytest.mark.parametrize("amax", [3.0, 1.0e6])
+def test_linear_fp32_range_guard_picks_the_split_on_the_device(amax):
+    """With a guard, mode 2 launches both operand splits and the device word decides: activations inside fp16's range
+    take the two-term fp16 split, anything larger (here 1e6: fp16 would overflow to inf) the three-term bf16 one."""
+    L = lib()
+    M, N, K = 2050, 512, 256
+    a = (rnd(M, K, seed=21) * amax).float()
+    w = rnd(N, K, seed=22, scale=K ** -0.5).float()
+    ref = a.double() @ w.double().T
+    a_d = a.to(DEV)
+    out = torch.empty((M, N), device=DEV)
+    measured = L.absmax(a_d)
+    with L.bounded_activations(guard=(measured, 16384.0)):
+        L.linear(a_d, w.to(DEV), None, out)
+    torch.cuda.synchronize()
+    assert abs(measured.item() - a.abs().max().item()) == 0.0
+    assert torch.isfinite(out).all()
+    assert relerr(out, ref) < 2e-6
+    assert L.set_f32_gemm(-1) == 1   # the mode is restored
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (130, 64, 64), (1000, 1536, 512), (129, 80, 2048),
                                    # the 256 x 256 ring kernel: 2, 4, 6 and 32 stages, ragged M
                                    (1030, 256, 64), (1500, 512, 128), (1100, 768, 192), (4099, 1536, 1024),
