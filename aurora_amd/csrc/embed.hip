@@ -68,9 +68,16 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
   const float loc = d.loc[c], inv = d.inv_scale[c];
   const float* src = d.src + b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)(wp * p.P) * d.sw;
   T* dst = reinterpret_cast<T*>(p.out) + row * p.Kpad + p.k_offset + (int64_t)vt * p.P * p.P + i * p.P;
-  for (int j = 0; j < p.P; ++j) {
-    const float z = (src[j * d.sw] - loc) * inv;
-    elem<T>::store(dst + j, patch_transform(z, d));
+  if (p.P == 4 && d.sw == 1 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0 && sizeof(T) == 4) {
+    // patch size 4, fp32 operand (the encoder): one 16-byte load and one 16-byte store per thread
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
+    *reinterpret_cast<f32x4*>(dst) = f32x4{patch_transform((s4.x - loc) * inv, d), patch_transform((s4.y - loc) * inv, d),
+                                            patch_transform((s4.z - loc) * inv, d), patch_transform((s4.w - loc) * inv, d)};
+  } else {
+    for (int j = 0; j < p.P; ++j) {
+      const float z = (src[j * d.sw] - loc) * inv;
+      elem<T>::store(dst + j, patch_transform(z, d));
+    }
   }
   // zero the K padding of this row (done by the threads of the last variable's last piece)
   if (q == q_per_row - 1 && p.k_offset + q_per_row * p.P == p.K_total) {
@@ -206,6 +213,7 @@ struct UnpatchVar {
 struct UnpatchArgs {
   UnpatchVar v[MAX_VARS];
   const float* y; int64_t ldy; int n_vars, B, n_lvl, Hp, Wp, P;
+  int vec4;   // P == 4 and every source / destination piece is 16-byte aligned
 };
 
 __global__ __launch_bounds__(256) void unpatchify_kernel(const UnpatchArgs p) {
@@ -236,8 +244,7 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const UnpatchArgs p) {
   const float* cosp = d.angle_col0 >= 0 ? row + d.angle_col0 : nullptr;   // wave: col0 = sin head, this = cos head
   const float* dens = d.dens_col0 >= 0 ? row + d.dens_col0 : nullptr;     // wave: density head
   const float* maskp = dens ? d.mask + hh * d.mask_sh + ww : nullptr;     // raw water-body mask plane
-  for (int j = 0; j < p.P; ++j) {
-    float z = src[j];
+  auto finish = [&](float z, int j) -> float {
     if (has_mod) z = z + (1.0f + mod[j]) * ((prev[j] - loc) * inv);
     if (cap1) z = fminf(z, 1.0f);
     if (d.clamp_min0) z = fmaxf(z, 0.f);
@@ -250,8 +257,14 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const UnpatchArgs p) {
       const bool water = maskp[j] > d.mask_thresh;
       z = (water && !(dens[j] < 0.f)) ? z : __int_as_float(0x7fc00000);
     }
-    dst[j] = z * sc + loc;
+    return z * sc + loc;
+  };
+  if (p.P == 4 && p.vec4) {   // patch size 4 (every model but the high-res / air-pollution ones): 16-byte pieces
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
+    *reinterpret_cast<f32x4*>(dst) = f32x4{finish(s4.x, 0), finish(s4.y, 1), finish(s4.z, 2), finish(s4.w, 3)};
+    return;
   }
+  for (int j = 0; j < p.P; ++j) dst[j] = finish(src[j], j);
 }
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -342,6 +355,10 @@ extern "C" int aurora_hip_unpatchify(const float* y, int64_t ldy, const aurora_u
                         desc[v].prev_sh, desc[v].inv_scale, desc[v].clamp_max1_levels, desc[v].angle_col0,
                         desc[v].dens_col0, desc[v].mask, desc[v].mask_sh, desc[v].mask_thresh};
   p.y = y; p.ldy = ldy; p.n_vars = n_vars; p.B = B; p.n_lvl = n_lvl; p.Hp = Hp; p.Wp = Wp; p.P = P;
+  bool al = P == 4 && (uintptr_t)y % 16 == 0 && ldy % 4 == 0;
+  for (int v = 0; v < n_vars && al; ++v)
+    al = (uintptr_t)desc[v].dst % 16 == 0 && desc[v].col0 % 4 == 0 && desc[v].lvl_stride % 4 == 0;
+  p.vec4 = al ? 1 : 0;
   const int64_t items = (int64_t)n_vars * B * n_lvl * Hp * P * Wp;
   AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "unpatchify: bad problem size");
   hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
