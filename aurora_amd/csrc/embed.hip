@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs
       mx[c] = -INFINITY;
       sum[c] = 0.f;
     }
+#pragma unroll 4   // (several keys' loads in flight; the online-softmax chain only orders the arithmetic)
     for (int j = 0; j < p.Lk; ++j) {
       const T* kp = kv0 + j * kv_step;
       float k4[4], v4[4];
