@@ -150,3 +150,22 @@ def test_halo_exchange_over_two_gloo_processes(shifted):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert ret.get(timeout=10) < 1e-10
+
+
+@pytest.mark.parametrize("res,world", [((4, 24, 24), 2), ((4, 45, 24), 8), ((4, 180, 360), 8)])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_interior_windows_need_no_halo_and_cover_most_of_a_band(res, world, shifted):
+    """The engine attends the windows that reference no halo row while the exchange is in flight
+    (`Engine._plans`: interior / boundary).  Interior windows must index owned rows only, the two classes
+    partition the plan, and at the benchmark geometry at least half of the windows are interior."""
+    rows = partition.band_rows([res], WINDOW, world)[0]
+    plans = partition.block_plans(res, WINDOW, shifted, tuple(rows))
+    for p in plans:
+        needs_halo = (p.tok >= p.n_own).any(axis=1)
+        interior, boundary = p.tok[~needs_halo], p.tok[needs_halo]
+        assert (interior < p.n_own).all()
+        assert len(interior) + len(boundary) == len(p.tok)
+        if not (p.recv or p.send):
+            assert not needs_halo.any()
+        if res == (4, 180, 360) and p.n_halo:
+            assert len(interior) >= 0.5 * len(p.tok)   # 8 ranks: 3 (or 2) of the 5 (4) shifted window rows per band
