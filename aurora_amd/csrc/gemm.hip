@@ -45,6 +45,7 @@ constexpr int BN = 128;       // output features per block
 constexpr int ROW_BYTES = 128;  // bytes of K per tile row
 constexpr int TILE_BYTES = 128 * ROW_BYTES;  // 16 KiB per operand per buffer
 constexpr int THREADS = 256;
+constexpr int ACT_GELU_SIG = 3;   // internal: GELU through the logistic form (bf16 results of the ring kernel only)
 
 struct LinearArgs {
   const char* A; int64_t lda_b;   // byte strides
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(THREADS, 2) void linear_kernel(const LinearArgs p) 
       v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
       v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
     }
-    if (p.act == AURORA_ACT_GELU) {
+    if (p.act == AURORA_ACT_GELU || p.act == ACT_GELU_SIG) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) v[t] = gelu_for<T>(v[t]);
     } else if (p.act == AURORA_ACT_SILU) {
@@ -344,7 +345,7 @@ __device__ __forceinline__ void epilogue_256(const LinearArgs& p, f32x4 (&acc)[4
       v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
       v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
     }
-    if (p.act == AURORA_ACT_GELU) {
+    if (p.act == AURORA_ACT_GELU || p.act == ACT_GELU_SIG) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) v[t] = gelu_for<T>(v[t]);
     } else if (p.act == AURORA_ACT_SILU) {
@@ -377,46 +378,54 @@ __device__ __forceinline__ void epilogue_256(const LinearArgs& p, f32x4 (&acc)[4
 // its stores and 16.9 us without) -- as long as half the tile's MFMA time.  The ring is dead after the main
 // loop, so each wave borrows 16 KiB of it; LDS rows are XOR-swizzled (piece ^ (row & 7)): conflict-free for the
 // b128 writes (8 rows per lane group) and reads (4 rows x 4 pieces per lane group).
+template <int PARTS>   // 1: a wave's 128 x 64 results in one pass (16 KiB of the dead ring); 2: two passes of 64 rows (8 KiB)
 __device__ __forceinline__ void epilogue_256_bf16_coalesced(const LinearArgs& p, f32x4 (&acc)[4][8], int64_t m0,
                                                             int n0, int wm, int wn, int wave, int lane, char* smem) {
   const int i16 = lane & 15, g = lane >> 4;
-  char* mine = smem + wave * 16384;
+  char* mine = smem + wave * (16384 / PARTS);
   const int nbase = n0 + wn * 64 + 16 * g;
   float bias_v[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
-#pragma unroll
-  for (int fm = 0; fm < 8; ++fm) {
-    float v[16];
-#pragma unroll
-    for (int fn = 0; fn < 4; ++fn) {
-      v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
-      v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
-      v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
-      v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
-    }
-    if (p.act == AURORA_ACT_GELU) {
-#pragma unroll
-      for (int t = 0; t < 16; ++t) v[t] = gelu_for<bf16_t>(v[t]);
-    } else if (p.act == AURORA_ACT_SILU) {
-#pragma unroll
-      for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
-    }
-    const int row = 16 * fm + i16, sw = row & 7;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      *reinterpret_cast<u32x4*>(mine + row * 128 + (((2 * g + q) ^ sw) << 4)) =
-          u32x4{pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
-                pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7])};
-  }
   const int rr = lane >> 3, cc = lane & 7;
   bf16_t* cbase = reinterpret_cast<bf16_t*>(p.C) + n0 + wn * 64 + cc * 8;
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int row = it * 8 + rr;
-    const u32x4 d = *reinterpret_cast<const u32x4*>(mine + row * 128 + ((cc ^ rr) << 4));
-    const int64_t m = m0 + wm * 128 + row;
-    if (m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
+  for (int part = 0; part < PARTS; ++part) {
+#pragma unroll
+    for (int f = 0; f < 8 / PARTS; ++f) {
+      const int fm = part * (8 / PARTS) + f;
+      float v[16];
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) {
+        v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
+        v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
+        v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
+        v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
+      }
+      if (p.act == AURORA_ACT_GELU) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = gelu_for<bf16_t>(v[t]);
+      } else if (p.act == ACT_GELU_SIG) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = gelu_sig(v[t]);
+      } else if (p.act == AURORA_ACT_SILU) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
+      }
+      const int row = 16 * f + i16, sw = row & 7;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        *reinterpret_cast<u32x4*>(mine + row * 128 + (((2 * g + q) ^ sw) << 4)) =
+            u32x4{pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
+                  pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7])};
+    }
+#pragma unroll
+    for (int it = 0; it < 16 / PARTS; ++it) {
+      const int row = it * 8 + rr;
+      const u32x4 d = *reinterpret_cast<const u32x4*>(mine + row * 128 + ((cc ^ rr) << 4));
+      const int64_t m = m0 + wm * 128 + part * (128 / PARTS) + row;
+      if (m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
+    }
   }
 }
 
@@ -480,7 +489,10 @@ __device__ __forceinline__ void epilogue_256_f32_coalesced(const LinearArgs& p, 
 // WN = number of wave columns: 4 -> 256 x 256 tile, 512 threads, one workgroup per CU (4-stage ring, 128 KiB) -- the
 // one in use.  (WN = 2, NST = 3 is a 256 x 128 tile with two workgroups per CU; measured 5-15 % slower on every
 // backbone shape -- co-resident workgroups start together and stay in phase -- and not instantiated.)
-template <typename T, int WN, int NST>
+// (Two co-resident 8-wave workgroups per CU -- a two-stage 64 KiB ring each -- do not fit: the 128 x 64 wave tile alone
+// holds 128 accumulator registers, the kernel needs ~250 of the 256 a wave gets at two waves per SIMD.)
+// PRIO: static s_setprio(1) for the second-dispatched half of the waves (the arbitration loser of every K-stage).
+template <typename T, int WN, int NST, int PRIO = 0>
 __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArgs p) {
   constexpr int NTHR = 128 * WN;
   constexpr int XP = (BM2 * 4) / NTHR;            // 16-byte pieces of the activation tile per thread and stage
@@ -493,6 +505,9 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  if constexpr (PRIO != 0) {
+    if (wave >= 2 * WN) __builtin_amdgcn_s_setprio(1);
+  }
 
   uint32_t tile_m, tile_n;
   tile_of_block(blockIdx.x, (uint32_t)p.n_blocks, (uint32_t)(p.n_blocks / p.tiles_n), (uint32_t)p.tiles_n, tile_m, tile_n);
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
   if constexpr (sizeof(T) == 2) {
     if (p.C2 == nullptr && p.res == nullptr && p.vec_store) {   // (uniform)
       __syncthreads();   // every wave is done with the ring
-      epilogue_256_bf16_coalesced(p, acc, m0, n0, wm, wn, wave, lane, smem);
+      epilogue_256_bf16_coalesced<1>(p, acc, m0, n0, wm, wn, wave, lane, smem);
       return;
     }
   } else if constexpr (WN == 4) {
@@ -895,19 +910,6 @@ int f32_mode() {
 }  // namespace
 
 namespace {
-int device_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    (void)hipGetDevice(&dev);
-    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  return n;
-}
-}  // namespace
-
-namespace {
 const float* g_guard = nullptr;
 float g_guard_limit = 0.f;
 }  // namespace
@@ -980,6 +982,7 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
     (void)hipFuncSetAttribute((const void*)linear_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<float, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     attr_done = true;
@@ -994,8 +997,15 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
       hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (dtype == AURORA_F32)
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-    else
-      hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    else {
+      static const int variant = [] { const char* e = getenv("AURORA_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+      static const int gelu_sig = [] { const char* e = getenv("AURORA_GELU_VARIANT"); return e ? atoi(e) : 0; }();
+      if (gelu_sig && act == AURORA_ACT_GELU) p.act = ACT_GELU_SIG;
+      if (variant == 1)
+        hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4, 1>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+      else
+        hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    }
   } else {
     if (dtype == AURORA_F32)
       hipLaunchKernelGGL(linear_kernel<float>, grid, dim3(THREADS), 4 * TILE_BYTES, as_stream(stream), p);

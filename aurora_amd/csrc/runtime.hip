@@ -24,6 +24,23 @@ int check_launch(const char* what) {
   return AURORA_OK;
 }
 
+int current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev;
+}
+
+int device_cus() {
+  static int cus[64] = {0};
+  const int dev = current_device() & 63;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
 namespace {
 
 template <typename S, typename D>
