@@ -16,7 +16,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "_lib" / "libaurora_hip.so"
-SOURCES = ("runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "embed.hip")
+SOURCES = ("runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "embed.hip", "model.hip")
 ARCH = "gfx950"
 
 

@@ -51,9 +51,34 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// Reductions over the four lanes l, l^16, l^32, l^48 that share a query: gfx950's row / half swaps
+// (v_permlane16_swap, v_permlane32_swap: one VALU slot each) instead of two ds_bpermute round trips through the LDS
+// crossbar.  swap(x, x) leaves {own-or-partner, partner-or-own} in the two results, so op(r.x, r.y) is the pairwise
+// reduction in every lane.
+typedef unsigned u32x2_sw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float quad_max(float v) {
+  u32x2_sw r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __builtin_fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __builtin_fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  u32x2_sw r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// Lanes g and g^1 (rows of 16 lanes) trade one of two packed d-tiles: even rows end up with d-tile `a` of both rows,
+// odd rows with d-tile `b` of both -- 16 consecutive bytes of the output row per lane (see WIDE below).
+__device__ __forceinline__ u32x4 pair_rows(u32x2 a, u32x2 b) {
+  const u32x2_sw x = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+  const u32x2_sw y = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+  return u32x4{x.x, y.x, x.y, y.y};
+}
+
 // FULL: the window has exactly 144 tokens (every stage of the published 0.25 / 0.1 / 0.4 degree
 // configurations): tile counts become compile-time constants.
-template <bool FULL>
+template <bool FULL, bool WIDE>
 __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * MAXN * 128 + MAXN * 4 + MAXN + 16];
   char* const s_k = smem;                 // [144][128 B], 16-byte pieces XOR-swizzled by row & 7
@@ -202,8 +227,7 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
 #pragma unroll
     for (int kt = 0; kt < MAXT; ++kt)
       if (FULL || kt < nt) mx = fmaxf(fmaxf(mx, fmaxf(st[kt].x, st[kt].y)), fmaxf(st[kt].z, st[kt].w));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = quad_max(mx);
     const float mxs = mx * c_scale;
     float sum = 0.f;
     u32x2 pk[MAXT];  // packed bf16 probabilities, kept as dwords (bit-cast at the MFMA)
@@ -220,13 +244,11 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
         pk[kt] = u32x2{0u, 0u};
       }
     }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    sum = quad_sum(sum);
     const float inv = __builtin_amdgcn_rcpf(sum);
 
     // ---- O^T = V^T P^T, 4 d-tiles of 16 ----
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    auto pv = [&](int dt) -> u32x2 {
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kt = 0; kt < MAXT; ++kt) {
@@ -236,9 +258,24 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
           o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, __builtin_bit_cast(bf16x4_t, pk[kt]), o, 0, 0, 0);
         }
       }
-      if (tq >= 0 && tq < p.L_out) {
-        const u32x2 packed = u32x2{pack_bf16x2(o.x * inv, o.y * inv), pack_bf16x2(o.z * inv, o.w * inv)};
-        *reinterpret_cast<u32x2*>(out + (int64_t)tq * p.D + col_q + dt * 16 + 4 * g) = packed;
+      return u32x2{pack_bf16x2(o.x * inv, o.y * inv), pack_bf16x2(o.z * inv, o.w * inv)};
+    };
+    const bool live = tq >= 0 && tq < p.L_out;
+    if constexpr (WIDE) {
+      // The C fragment gives a lane 4 consecutive d (8 bytes) per d-tile.  Lanes g, g^1 trade halves of two d-tiles so
+      // that every lane stores 16 bytes and four lanes cover 64 contiguous bytes of the output row.
+      const bool odd = (g & 1) != 0;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const u32x4 v = pair_rows(pv(2 * a), pv(2 * a + 1));
+        const int col = col_q + 32 * a + (odd ? 16 + 4 * (g - 1) : 4 * g);
+        if (live) *reinterpret_cast<u32x4*>(out + (int64_t)tq * p.D + col) = v;
+      }
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const u32x2 packed = pv(dt);
+        if (live) *reinterpret_cast<u32x2*>(out + (int64_t)tq * p.D + col_q + dt * 16 + 4 * g) = packed;
       }
     }
   }
@@ -451,8 +488,7 @@ __global__ __launch_bounds__(192, 3) void window_attention_bf16_pipe(const AttnA
 #pragma unroll
       for (int kt = 0; kt < MAXT; ++kt)
         if (FULL || kt < nt) mx = fmaxf(fmaxf(mx, fmaxf(st[kt].x, st[kt].y)), fmaxf(st[kt].z, st[kt].w));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = quad_max(mx);
       const float mxs = mx * c_scale;
       float sum = 0.f;
       u32x2 pk[MAXT];  // packed bf16 probabilities, kept as dwords (bit-cast at the MFMA)
@@ -469,8 +505,7 @@ __global__ __launch_bounds__(192, 3) void window_attention_bf16_pipe(const AttnA
           pk[kt] = u32x2{0u, 0u};
         }
       }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = quad_sum(sum);
       const float inv = __builtin_amdgcn_rcpf(sum);
 
       // ---- O^T = V^T P^T, 4 d-tiles of 16 ----
@@ -491,10 +526,7 @@ __global__ __launch_bounds__(192, 3) void window_attention_bf16_pipe(const AttnA
         const bool odd = (g & 1) != 0;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          const u32x2 p0 = pv(2 * a), p1 = pv(2 * a + 1);
-          const u32x2 send = odd ? p0 : p1;
-          const u32x2 recv = u32x2{(uint32_t)__shfl_xor((int)send.x, 16, 64), (uint32_t)__shfl_xor((int)send.y, 16, 64)};
-          const u32x4 v = odd ? u32x4{recv.x, recv.y, p1.x, p1.y} : u32x4{p0.x, p0.y, recv.x, recv.y};
+          const u32x4 v = pair_rows(pv(2 * a), pv(2 * a + 1));
           const int col = col_q + 32 * a + (odd ? 16 + 4 * (g - 1) : 4 * g);
           if (live) *reinterpret_cast<u32x4*>(out + (int64_t)tq * p.D + col) = v;
         }
@@ -619,12 +651,14 @@ extern "C" int aurora_hip_window_attention(const void* qkv, const float* qkv_bia
   AURORA_CHECK_ARG(blocks < ((int64_t)1 << 31), "window_attention: grid too large");
   AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens, L_out};
   if (dtype == AURORA_BF16) {
-    static const int variant = [] { const char* e = getenv("AURORA_ATTN_VARIANT"); return e ? atoi(e) : 2; }();
-    if (variant == 0) {   // one workgroup per (window, head), no pipelining: kept for A/B measurements
-      if (win_tokens == MAXN)
-        hipLaunchKernelGGL(window_attention_bf16<true>, dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+    static const int variant = [] { const char* e = getenv("AURORA_ATTN_VARIANT"); return e ? atoi(e) : 3; }();
+    if (variant == 0 || variant == 3) {   // one workgroup per (window, head); 3: 16-byte result stores
+      if (win_tokens != MAXN)
+        hipLaunchKernelGGL((window_attention_bf16<false, true>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+      else if (variant == 0)
+        hipLaunchKernelGGL((window_attention_bf16<true, false>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
       else
-        hipLaunchKernelGGL(window_attention_bf16<false>, dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+        hipLaunchKernelGGL((window_attention_bf16<true, true>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
     } else {
       // persistent: 4 workgroups per CU (LDS-limited), grid-stride over the (batch, window, head) items
       const int64_t resident = (int64_t)device_cus() * 4;

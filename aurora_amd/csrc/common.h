@@ -111,10 +111,10 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// Exact-erf GELU to ~4e-7 absolute (Abramowitz & Stegun 7.1.26, |erf error| <= 1.5e-7) in ~14 VALU
+// Exact-erf GELU to ~4e-7 absolute (Abramowitz & Stegun 7.1.26, |erf error| <= 1.5e-7) in ~17 VALU
 // ops instead of erff's ~60: Phi(x) = 1 - q (x >= 0) or q (x < 0) with q = poly(t) * exp(-x^2/2) / 2,
-// t = 1/(1 + p|x|/sqrt2) -- written without the 1 - erf cancellation.  Used where the result is
-// rounded to bf16 (ulp 4e-3) anyway; fp32 outputs keep erff.
+// t = 1/(1 + p|x|/sqrt2) -- written without the 1 - erf cancellation.  Used for the fp32 results of the
+// operand-splitting GEMMs (packed form below); the native-fp32 GEMM keeps erff, bf16 results use gelu_sig.
 __device__ __forceinline__ float gelu_erf_fast(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
@@ -137,9 +137,37 @@ __device__ __forceinline__ float gelu_sig(float x) {
   const float e = __builtin_amdgcn_exp2f(xc * t);          // exp(-2 q(x))
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// Two values at a time: the polynomial part runs on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32:
+// two lanes' worth of fp32 per issue slot).  A VALU instruction costs a wave ~4 cycles of its SIMD's issue, a 256 x 256
+// tile has 256 values per lane, and nothing else runs on the CU during a GEMM epilogue -- the activation is 8 us of a
+// 22 us stage-0 fc1 tile in its scalar form.
+__device__ __forceinline__ f32x2_hw gelu_sig2(f32x2_hw x) {
+  const f32x2_hw xc = {__builtin_amdgcn_fmed3f(x.x, -9.0f, 9.0f), __builtin_amdgcn_fmed3f(x.y, -9.0f, 9.0f)};
+  const f32x2_hw x2 = xc * xc;
+  f32x2_hw t = __builtin_elementwise_fma(x2, f32x2_hw{1.0142631e-3f, 1.0142631e-3f}, f32x2_hw{-1.0677572e-1f, -1.0677572e-1f});
+  t = __builtin_elementwise_fma(t, x2, f32x2_hw{-2.3011213f, -2.3011213f});
+  const f32x2_hw u = xc * t;
+  const f32x2_hw d = f32x2_hw{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)} + f32x2_hw{1.0f, 1.0f};
+  return x * f32x2_hw{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+// Packed form of gelu_erf_fast (|error| <= 7.5e-8 |x|, i.e. a few fp32 ulps): the fp32 linears that run on the matrix
+// pipe by operand splitting use it for their fp32 results -- erff costs ~60 VALU issue slots per value, and the
+// decoder's fc1 alone applies GELU to 1.7 x 10^9 values per step.
+__device__ __forceinline__ f32x2_hw gelu_erf_fast2(f32x2_hw x) {
+  const f32x2_hw z = f32x2_hw{fabsf(x.x), fabsf(x.y)} * f32x2_hw{0.70710678118654752440f, 0.70710678118654752440f};
+  const f32x2_hw den = __builtin_elementwise_fma(z, f32x2_hw{0.3275911f, 0.3275911f}, f32x2_hw{1.0f, 1.0f});
+  const f32x2_hw t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  f32x2_hw poly = __builtin_elementwise_fma(t, f32x2_hw{1.061405429f, 1.061405429f}, f32x2_hw{-1.453152027f, -1.453152027f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2_hw{1.421413741f, 1.421413741f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2_hw{-0.284496736f, -0.284496736f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2_hw{0.254829592f, 0.254829592f});
+  const f32x2_hw a = z * z * f32x2_hw{-1.4426950408889634f, -1.4426950408889634f};   // -z^2 log2(e)
+  const f32x2_hw q = poly * t * f32x2_hw{0.5f, 0.5f} * f32x2_hw{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+  return x * f32x2_hw{x.x >= 0.f ? 1.0f - q.x : q.x, x.y >= 0.f ? 1.0f - q.y : q.y};
+}
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
-template <> __device__ __forceinline__ float gelu_for<uint16_t>(float x) { return gelu_erf_fast(x); }
+template <> __device__ __forceinline__ float gelu_for<uint16_t>(float x) { return gelu_sig(x); }   // every bf16 epilogue: same bits whatever the tile shape
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

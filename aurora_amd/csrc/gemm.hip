@@ -45,7 +45,7 @@ constexpr int BN = 128;       // output features per block
 constexpr int ROW_BYTES = 128;  // bytes of K per tile row
 constexpr int TILE_BYTES = 128 * ROW_BYTES;  // 16 KiB per operand per buffer
 constexpr int THREADS = 256;
-constexpr int ACT_GELU_SIG = 3;   // internal: GELU through the logistic form (bf16 results of the ring kernel only)
+constexpr int ACT_GELU_FAST = 4;  // internal: fp32 results of the operand-splitting kernels, erf to 1.5e-7 (packed)
 
 struct LinearArgs {
   const char* A; int64_t lda_b;   // byte strides
@@ -240,9 +240,12 @@ __global__ __launch_bounds__(THREADS, 2) void linear_kernel(const LinearArgs p) 
       v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
       v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
     }
-    if (p.act == AURORA_ACT_GELU || p.act == ACT_GELU_SIG) {
+    if (p.act == AURORA_ACT_GELU) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) v[t] = gelu_for<T>(v[t]);
+    } else if (p.act == ACT_GELU_FAST) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = gelu_erf_fast(v[t]);
     } else if (p.act == AURORA_ACT_SILU) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
@@ -345,9 +348,12 @@ __device__ __forceinline__ void epilogue_256(const LinearArgs& p, f32x4 (&acc)[4
       v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
       v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
     }
-    if (p.act == AURORA_ACT_GELU || p.act == ACT_GELU_SIG) {
+    if (p.act == AURORA_ACT_GELU) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) v[t] = gelu_for<T>(v[t]);
+    } else if (p.act == ACT_GELU_FAST) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = gelu_erf_fast(v[t]);
     } else if (p.act == AURORA_ACT_SILU) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
@@ -402,12 +408,13 @@ __device__ __forceinline__ void epilogue_256_bf16_coalesced(const LinearArgs& p,
         v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
         v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
       }
-      if (p.act == AURORA_ACT_GELU) {
+      if (p.act == AURORA_ACT_GELU) {   // (packed form of gelu_for<bf16_t>: same operations, same bits)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = gelu_for<bf16_t>(v[t]);
-      } else if (p.act == ACT_GELU_SIG) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = gelu_sig(v[t]);
+        for (int t = 0; t < 16; t += 2) {
+          const f32x2_hw r = gelu_sig2(f32x2_hw{v[t], v[t + 1]});
+          v[t] = r.x;
+          v[t + 1] = r.y;
+        }
       } else if (p.act == AURORA_ACT_SILU) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
@@ -457,6 +464,13 @@ __device__ __forceinline__ void epilogue_256_f32_coalesced(const LinearArgs& p, 
       if (p.act == AURORA_ACT_GELU) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) v[t] = gelu_for<float>(v[t]);
+      } else if (p.act == ACT_GELU_FAST) {
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+          const f32x2_hw r = gelu_erf_fast2(f32x2_hw{v[t], v[t + 1]});
+          v[t] = r.x;
+          v[t + 1] = r.y;
+        }
       } else if (p.act == AURORA_ACT_SILU) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
@@ -647,6 +661,234 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
 
 
 // =================================================================================================
+// Persistent form of linear_kernel_256<bf16, 4, 4> for the plain bf16 -> bf16 linears (qkv, proj, fc1, fc2 of every
+// block: no residual, no second output, N % 256 == 0, K >= 256).
+//
+// Why: a 256 x 256 tile at K = 512 spends 14 us in its main loop and 6-8 us outside it -- ~2.5 us until the first
+// K-stage of a cold tile has arrived from HBM, the rest in the epilogue -- and with one workgroup per CU nothing else
+// runs meanwhile.  Here a workgroup keeps its CU and walks over tiles (tile = block + k * grid); when a tile's last
+// MFMA has issued it starts the NEXT tile's first four K-stages (16 LDS-DMA instructions per lane) and only then
+// converts, transposes and stores its results, so the cold-start latency of tile i+1 hides under the epilogue of tile i.
+// Two things make that legal:
+//   * the ring (128 KiB) is busy with the next tile, so the result transpose gets its own 32 KiB behind it (160 KiB of
+//     LDS in total) and runs in four passes of 32 rows per wave;
+//   * vmcnt retires IN ORDER (gfx9: loads and stores share the counter), so the 16 result stores a lane issues AFTER
+//     the next prologue sit between that prologue and the stages issued in the loop.  The first three steps of the
+//     next main loop therefore wait with their immediates raised by 16 -- "stage kt+1 has landed" = at most (younger
+//     DMA + 16 stores) outstanding -- and from the fourth step on the stores are older than everything waited for.
+//     That count is only known when all 16 stores were issued, i.e. for tiles with 256 valid rows; the ragged last
+//     m-tile drains the counter after its epilogue instead.
+// Bias values are fetched before the last K-stage's wait and pinned there (hipcc would otherwise wait vmcnt(0) at their
+// first use, draining the prologue it has just issued).
+// =================================================================================================
+constexpr int PERSIST_LDS = NSTAGE2 * STAGE2 + 8 * 2048 + 2 * 2048;   // ring | result transpose (2 KiB per wave) | bias x 2
+
+template <int PRIO>
+__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256p(const LinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  if constexpr (PRIO != 0) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
+  const int i16 = lane & 15, g = lane >> 4;
+  int off_x[8], off_w[4];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const int row = wm * 128 + 16 * f + i16;
+    off_x[f] = row * ROW2 + ((g ^ swz2_x(row)) << 4);
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int row = wn * 64 + 16 * (i16 >> 2) + 4 * f + (i16 & 3);
+    off_w[f] = OPER2 + row * ROW2 + ((g ^ swz2_w(row)) << 4);
+  }
+  const uint32_t n_tiles = (uint32_t)p.n_blocks, tiles_n = (uint32_t)p.tiles_n, tiles_m = n_tiles / tiles_n;
+  const int nt = p.k_tiles;   // >= 8 (dispatch), even
+
+  const char* src_x[2];
+  const char* src_w[2];
+  int64_t m0 = 0;
+  int n0 = 0;
+  // (`opaque`: per-lane constants of the tile loop -- staging rows, swizzles, epilogue offsets -- are recomputed per tile;
+  // hoisted out of the loop they would be spilled, and a spill RELOAD is a vector-memory operation whose wait drains
+  // the LDS-DMA queue, i.e. the very prologue the epilogue is supposed to run under)
+  auto lane_now = []() {   // the lane id, rematerialised (asm volatile is neither hoisted nor merged)
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  auto locate = [&](uint32_t tile) {
+    uint32_t tile_m, tile_n;
+    tile_of_block(tile, n_tiles, tiles_m, tiles_n, tile_m, tile_n);
+    m0 = (int64_t)tile_m * BM2;
+    n0 = (int)tile_n * BN2;
+    const int tid_l = wave * 64 + lane_now();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int id = r * THREADS2 + tid_l;
+      const int row = id >> 2, c = id & 3;
+      int64_t gm = m0 + row;
+      gm = gm < p.M ? gm : p.M - 1;
+      src_x[r] = p.A + gm * p.lda_b + ((c ^ swz2_x(row)) << 4);
+      src_w[r] = p.W + (int64_t)(n0 + row) * p.ldw_b + ((c ^ swz2_w(row)) << 4);
+    }
+  };
+  auto stage = [&](int kt) {
+    const int64_t koff = (int64_t)kt * ROW2;
+    char* base = smem + (kt & (NSTAGE2 - 1)) * STAGE2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[r] + koff),
+                                       (lds_ptr_t)(base + (r * THREADS2 + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
+                                       (lds_ptr_t)(base + OPER2 + (r * THREADS2 + wave * 64) * 16), 16, 0, 0);
+  };
+
+  f32x4 acc[4][8];  // [fn][fm]
+  auto read_frags = [&](int kt, u32x4 (&fw)[4], u32x4 (&fx)[8]) {
+    const char* buf = smem + (kt & (NSTAGE2 - 1)) * STAGE2;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fw[f] = *reinterpret_cast<const u32x4*>(buf + off_w[f]);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) fx[f] = *reinterpret_cast<const u32x4*>(buf + off_x[f]);
+  };
+  auto mma_rows = [&](u32x4 (&cw)[4], u32x4 (&cx)[8], int fm_lo, int fm_hi) {
+#pragma unroll
+    for (int fm = fm_lo; fm < fm_hi; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = Mma<bf16_t>::run(cw[fn], cx[fm], acc[fn][fm]);
+  };
+  bool stores_pending = false;   // 16 result stores of the previous tile sit behind this tile's prologue in the queue
+  auto step = [&](int kt, u32x4 (&cw)[4], u32x4 (&cx)[8], u32x4 (&nw)[4], u32x4 (&nx)[8]) {
+    mma_rows(cw, cx, 0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    // my pieces of stage kt+1 have landed once only the younger operations remain outstanding
+    if (kt < 3 && stores_pending) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // 2 stages + 16 stores
+    else if (kt + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // RAW: stage kt+1 complete.  WAR: everyone has read stage kt.
+    asm volatile("" ::: "memory");
+    if (kt + NSTAGE2 < nt) stage(kt + NSTAGE2);  // into stage kt's buffer
+    read_frags(kt + 1, nw, nx);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_rows(cw, cx, 2, 8);
+  };
+
+  // A tile's prologue: its bias slice first (one 4-byte LDS-DMA per lane: 64 features per wave, oldest in the queue, so
+  // it has landed whenever stage 0 has), then the first four K-stages.
+  char* const s_bias = smem + NSTAGE2 * STAGE2 + 8 * 2048;   // [2][8 waves][64 floats]
+  int parity = 0;
+  auto prologue = [&](int par) {
+    if (p.bias)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n0 + wn * 64 + lane_now()),
+                                       (lds_ptr_t)(s_bias + par * 2048 + wave * 256), 4, 0, 0);
+    stage(0);
+    stage(1);
+    stage(2);
+    stage(3);
+  };
+  uint32_t tile = blockIdx.x;
+  locate(tile);
+  prologue(0);
+  for (;;) {
+    const int64_t cm0 = m0;   // this tile (locate() moves m0 / n0 on to the next one before the epilogue)
+    const int cn0 = n0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (stores_pending) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");   // stage 0 landed: 3 stages + 16 stores younger
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 fwA[4], fxA[8], fwB[4], fxB[8];
+    read_frags(0, fwA, fxA);
+    for (int kt = 0; kt + 2 < nt; kt += 2) {
+      step(kt, fwA, fxA, fwB, fxB);
+      step(kt + 1, fwB, fxB, fwA, fxA);
+    }
+    step(nt - 2, fwA, fxA, fwB, fxB);  // fetches the last stage; its wait is vmcnt(0)
+    mma_rows(fwB, fxB, 0, 8);
+
+    // ---- next tile's prologue, then this tile's epilogue ----
+    const uint32_t next = tile + gridDim.x;
+    const bool has_next = next < n_tiles;
+    __builtin_amdgcn_s_barrier();   // every wave has read the last stage: the ring is free
+    asm volatile("" ::: "memory");
+    if (has_next) {
+      locate(next);
+      prologue(parity ^ 1);
+    }
+    const bool full_rows = cm0 + BM2 <= p.M;
+    const int lane_l = lane_now();
+    const int i16 = lane_l & 15, g = lane_l >> 4;   // (shadow the loop-invariant copies)
+    float bias_v[16];   // this lane's 16 output features, out of this tile's LDS slice
+    {
+      const f32x4* bs = reinterpret_cast<const f32x4*>(s_bias + parity * 2048 + wave * 256 + g * 64);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = p.bias ? bs[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias_v[4 * q] = bv.x; bias_v[4 * q + 1] = bv.y; bias_v[4 * q + 2] = bv.z; bias_v[4 * q + 3] = bv.w;
+      }
+    }
+    parity ^= 1;
+    char* mine = smem + NSTAGE2 * STAGE2 + wave * 2048;
+    const int rr = lane_l >> 3, cc = lane_l & 7;
+    bf16_t* cbase = reinterpret_cast<bf16_t*>(p.C) + cn0 + wn * 64 + cc * 8;
+#pragma unroll
+    for (int part = 0; part < 8; ++part) {   // 16 rows (one fragment row) per pass through the wave's 2 KiB
+      {
+        const int fm = part;
+        float v[16];
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
+          v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
+          v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
+          v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
+        }
+        if (p.act == AURORA_ACT_GELU) {
+#pragma unroll
+          for (int t = 0; t < 16; t += 2) {
+            const f32x2_hw r = gelu_sig2(f32x2_hw{v[t], v[t + 1]});
+            v[t] = r.x;
+            v[t + 1] = r.y;
+          }
+        } else if (p.act == AURORA_ACT_SILU) {
+#pragma unroll
+          for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
+        }
+        const int row = i16, sw = row & 7;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          *reinterpret_cast<u32x4*>(mine + row * 128 + (((2 * g + q) ^ sw) << 4)) =
+              u32x4{pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
+                    pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7])};
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + rr;
+        const u32x4 d = *reinterpret_cast<const u32x4*>(mine + row * 128 + ((cc ^ rr) << 4));
+        const int64_t m = cm0 + wm * 128 + part * 16 + row;
+        if (full_rows) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
+        else if (m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
+      }
+    }
+    if (!has_next) break;
+    if (!full_rows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // unknown number of stores: drain
+    stores_pending = full_rows;
+    tile = next;
+  }
+}
+
+
+// =================================================================================================
 // fp32 linear layers on the bf16 matrix pipe: "3 x bf16" operand splitting.
 //
 // gfx950 multiplies bf16 sixteen times faster than fp32 on the matrix cores (v_mfma_f32_16x16x32_bf16:
@@ -705,7 +947,7 @@ __device__ __forceinline__ f32x4 mma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 // fp16's range: a_h overflows at |a| >= 65520, and a_l is a subnormal for |a| < 0.25, i.e. carries an ABSOLUTE error
 // of up to 3e-8.  The weight operand is therefore scaled by 2^6 on the fly (nn.Linear weights are O(1e-2); the
 // accumulators are scaled back exactly in the epilogue) and the variant is only used where the caller vouches for
-// activations that are bounded by construction (aurora_hip_set_f32_gemm(2): LayerNorm outputs and their GELU'd linears).
+// activations that are bounded by construction (f32_gemm = 2 of aurora_hip_linear_ex: LayerNorm outputs and their GELU'd linears).
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -897,40 +1139,37 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
 using namespace aurora;
 
 namespace {
+// Process default of how large fp32 linears are multiplied (read once from AURORA_F32_GEMM, never changed afterwards):
 // 0: native fp32 MFMA (v_mfma_f32_16x16x4_f32); 1: 3 x bf16 operand splitting (default); 2: 2 x fp16 splitting.
-int g_f32_mode = -1;
-int f32_mode() {
-  if (g_f32_mode < 0) {
+int default_f32_mode() {
+  static const int mode = [] {
     const char* e = getenv("AURORA_F32_GEMM");
-    g_f32_mode = !e ? 1 : (e[0] == 'n' || e[0] == '0') ? 0 : (e[0] == 'f' || e[0] == '2') ? 2 : 1;   // native | bf16 | f16
-  }
-  return g_f32_mode;
+    return !e ? 1 : (e[0] == 'n' || e[0] == '0') ? 0 : (e[0] == 'f' || e[0] == '2') ? 2 : 1;   // native | bf16 | f16
+  }();
+  return mode;
 }
-
 }  // namespace
 
-namespace {
-const float* g_guard = nullptr;
-float g_guard_limit = 0.f;
-}  // namespace
-
-extern "C" int aurora_hip_set_f32_guard(const float* device_absmax, float limit) {
-  g_guard = device_absmax;
-  g_guard_limit = limit;
-  return AURORA_OK;
-}
-
-extern "C" int aurora_hip_set_f32_gemm(int mode) {
-  const int prev = f32_mode();
-  if (mode >= 0 && mode <= 2) g_f32_mode = mode;
-  return prev;
-}
+extern "C" int aurora_hip_default_f32_gemm(void) { return default_f32_mode(); }
 
 extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int64_t ldw,
                                  const float* bias, void* C, int64_t ldc, void* C2, int64_t ldc2,
                                  const float* residual, int64_t ldr, int64_t M, int N, int K,
                                  int dtype, int act, void* stream) {
+  return aurora_hip_linear_ex(A, lda, W, ldw, bias, C, ldc, C2, ldc2, residual, ldr, M, N, K, dtype, act, -1, nullptr,
+                              0.f, stream);
+}
+
+extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, int64_t ldw,
+                                    const float* bias, void* C, int64_t ldc, void* C2, int64_t ldc2,
+                                    const float* residual, int64_t ldr, int64_t M, int N, int K,
+                                    int dtype, int act, int f32_gemm, const float* guard, float guard_limit,
+                                    void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "linear: bad dtype %d", dtype);
+  AURORA_CHECK_ARG(f32_gemm >= -1 && f32_gemm <= 2, "linear: bad fp32 GEMM mode %d", f32_gemm);
+  const int mode = f32_gemm < 0 ? default_f32_mode() : f32_gemm;
+  const float* const g_guard = mode == 2 ? guard : nullptr;
+  const float g_guard_limit = guard_limit;
   AURORA_CHECK_ARG(M > 0 && N > 0 && K > 0, "linear: empty problem M=%lld N=%d K=%d", (long long)M, N, K);
   const int es = dtype == AURORA_F32 ? 4 : 2, es2 = dtype == AURORA_F32 ? 2 : 4;
   AURORA_CHECK_ARG(((int64_t)K * es) % ROW_BYTES == 0,
@@ -945,7 +1184,7 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
   // Big backbone shapes take the 256 x 256 ring kernel; everything else the 128 x 128 one.
   // (fp32 in split mode: the kernel choice must not depend on M, or a latitude band of a sharded model
   // would round differently from the same rows of the un-sharded one.)
-  const bool split = dtype == AURORA_F32 && f32_mode() >= 1;
+  const bool split = dtype == AURORA_F32 && mode >= 1;
   bool big = (M >= 1024 || split) && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
   if (big && !split) {
     // Few tiles (a latitude band of a sharded model, the coarse stages): 256 x 256 tiles leave CUs idle or end in a
@@ -971,37 +1210,51 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
   if (C2) vec = vec && ((uintptr_t)C2 % 16) == 0 && (ldc2 * es2) % 16 == 0;
   if (residual) vec = vec && ((uintptr_t)residual % 16) == 0 && (ldr * 4) % 16 == 0;
   p.vec_store = vec ? 1 : 0;
-  p.guard = (split && f32_mode() == 2) ? g_guard : nullptr;
+  if (split && big && act == AURORA_ACT_GELU) p.act = ACT_GELU_FAST;
+  p.guard = split ? g_guard : nullptr;
   p.guard_limit = g_guard_limit;
   AURORA_CHECK_ARG(p.n_blocks < (int64_t)1 << 31, "linear: too many tiles");
 
   dim3 grid((unsigned)p.n_blocks);
-  static bool attr_done = false;
+  static bool attr_done_dev[64] = {false};   // function attributes are per device
+  bool& attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)linear_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     (void)hipFuncSetAttribute((const void*)linear_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<float, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     attr_done = true;
   }
   if (big) {
-    if (split && f32_mode() == 2 && g_guard != nullptr) {   // both variants; the device word picks one
+    if (split && mode == 2 && g_guard != nullptr) {   // both variants; the device word picks one
       hipLaunchKernelGGL(linear_kernel_256_f32x3<2>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
       hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-    } else if (split && f32_mode() == 2)
+    } else if (split && mode == 2)
       hipLaunchKernelGGL(linear_kernel_256_f32x3<2>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (split)
       hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (dtype == AURORA_F32)
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else {
-      static const int variant = [] { const char* e = getenv("AURORA_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
-      static const int gelu_sig = [] { const char* e = getenv("AURORA_GELU_VARIANT"); return e ? atoi(e) : 0; }();
-      if (gelu_sig && act == AURORA_ACT_GELU) p.act = ACT_GELU_SIG;
-      if (variant == 1)
+      static const int variant = [] { const char* e = getenv("AURORA_GEMM_VARIANT"); return e ? atoi(e) : 4; }();
+      // Persistent form where it wins (measured, profiles/r02_ab_gemm_variants.log: +3..6 % for N >= 1024 and K <= 2048,
+      // -1..4 % on the long-K / two-n-tile shapes, whose tiles spend little of their time outside the main loop).
+      // AURORA_GEMM_VARIANT: 0 ring kernel, 1 ring + static wave priority, 2 / 3 the same with the persistent form
+      // wherever it is legal (A/B), default 4 = 3 under the shape rule.
+      const bool plain = C2 == nullptr && residual == nullptr && vec && N % BN2 == 0 && p.k_tiles >= 8;
+      const bool wins = N >= 1024 && K <= 2048;
+      if (variant >= 2 && plain && p.n_blocks > device_cus() && (variant != 4 || wins)) {
+        const dim3 pgrid((unsigned)device_cus());   // one workgroup per CU walks over the tiles
+        if (variant == 2)
+          hipLaunchKernelGGL(linear_kernel_256p<0>, pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
+        else
+          hipLaunchKernelGGL(linear_kernel_256p<1>, pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
+      } else if (variant == 1 || variant >= 3)
         hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4, 1>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
       else
         hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);

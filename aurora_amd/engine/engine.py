@@ -40,7 +40,7 @@ import torch
 
 from aurora_amd import normalisation
 from aurora_amd.batch import BandBatch, Batch, Metadata, derive_metadata
-from aurora_amd.engine import encodings, geometry, lib, partition
+from aurora_amd.engine import encodings, geometry, lib, native, partition
 from aurora_amd.model.schema import DYNAMIC_VARS, LORA_ALPHA, LORA_RANK
 from aurora_amd.normalisation import level_to_str
 
@@ -115,6 +115,15 @@ class Engine:
         self._time_bufs: dict = {}     # B -> persistent device buffers of the clock-dependent inputs
         self._pinned: dict = {}        # (shape, dtype) -> ring of pinned staging buffers for `_upload`
         self._capturing = False        # True while a hipGraph of the step is being captured
+        # The ERA5 model family on one device: the whole step is sequenced by the C-ABI handle (csrc/model.hip); this
+        # class then only converts Batches to raw pointers.  AURORA_NATIVE_STEP=0 keeps the Python sequencing below
+        # (same kernels, same order; used by tests to compare the two).
+        self.native = None
+        if (native.supports(model) and (self.shard is None or self.shard.world == 1)
+                and os.environ.get("AURORA_NATIVE_STEP", "1") != "0"):
+            self.native = native.NativeModel(model)
+            self.blocks = self._block_list()
+            return
         self._pack_static()
 
     # ---------------------------------------------------------------------------------------
@@ -313,7 +322,7 @@ class Engine:
         """
         # (storage address + shape, not object identity: `Batch.crop` makes a fresh view of the same coordinates
         # on every call, and a miss costs a device->host copy, i.e. a full synchronisation per step)
-        ident = (lat.data_ptr(), tuple(lat.shape), lon.data_ptr(), tuple(lon.shape))
+        ident = (lat.data_ptr(), tuple(lat.shape), native._version(lat), lon.data_ptr(), tuple(lon.shape), native._version(lon))
         hit = self._grid_cache.get("ident")
         if hit is not None and hit[0] == ident:
             return hit[3]
@@ -401,9 +410,14 @@ class Engine:
     # the step
     # ---------------------------------------------------------------------------------------
     @torch.no_grad()
-    def step(self, batch: Batch) -> Batch:
-        """One forecast step.  With sharding, halo exchanges run as NCCL/RCCL point-to-point groups."""
-        gen = self.step_gen(batch)
+    def step(self, batch: Batch, out=None) -> Batch:
+        """One forecast step.  With sharding, halo exchanges run as NCCL/RCCL point-to-point groups.
+        `out`: optional destination tensors of the prediction, see `Aurora.forward`."""
+        if self.native is not None:
+            done = self._native_step(batch, out)
+            if done is not None:
+                return done
+        gen = self.step_gen(batch, out)
         pending = []
         try:
             req = next(gen)
@@ -417,6 +431,38 @@ class Engine:
                 req = gen.send(None)
         except StopIteration as done:
             return done.value
+
+    # -- per-launch timing (bench.py, tools): HIP events on the launch stream -----------------------------------
+    def profile_start(self, only=None) -> None:
+        """Bracket every launch (or the kernels named in `only`) with HIP events until `profile_stop`."""
+        if self.native is not None:
+            self.native.profile_begin(only)
+        lib.profile_start(only)
+
+    def profile_stop(self) -> dict:
+        """{kernel: {"launches", "ms", "work"}}: launches issued by the C-ABI handle plus those issued from Python."""
+        out = lib.profile_stop()
+        if self.native is not None:
+            for k, v in self.native.profile_end().items():
+                d = out.setdefault(k, {"launches": 0, "ms": 0.0, "work": 0.0})
+                for f in d:
+                    d[f] += v[f]
+        return out
+
+    def _native_step(self, batch: Batch, out=None) -> Optional[Batch]:
+        """The step through the C-ABI handle; None if this batch needs the Python sequencing (a variable subset, or
+        latitude / longitude matrices)."""
+        if self.is_stale():
+            raise RuntimeError("model parameters changed after packing: call model._engine = None first")
+        if isinstance(batch, BandBatch) or not self.native.accepts(batch):
+            if not hasattr(self, "enc_layers"):
+                self._pack_static()
+            return None
+        cfg = self.cfg
+        batch = batch.type(F32).crop(cfg.patch_size).to(self.device)
+        T = next(iter(batch.surf_vars.values())).shape[1]
+        assert T <= cfg.max_history_size, f"{T} > {cfg.max_history_size}."
+        return self.native.step(batch, upload_time=not self._capturing, out=out)
 
     def _exchange(self, req: Exchange) -> list:
         """Start one halo exchange with torch.distributed point-to-point operations; returns the works that are
@@ -449,7 +495,7 @@ class Engine:
             work.wait()
         return []
 
-    def step_gen(self, batch: Batch):
+    def step_gen(self, batch: Batch, out=None):
         """Generator form of the step: yields `Exchange` requests (sharded mode only) and returns the
         prediction.  `step()` drives it with RCCL; tests drive several ranks in one process."""
         model, cfg = self.model, self.cfg
@@ -513,11 +559,11 @@ class Engine:
         mark("encoder")
         x_cat = yield from self._backbone(x_f, x_b, B, patch_res, md.rollout_step, rows)
         mark("backbone")
-        out = self._decode(x_cat, batch, B, H, W, Hp, Wp, levels)
+        pred = self._decode(x_cat, batch, B, H, W, Hp, Wp, levels, out)
         mark("decoder")
         if sh is not None and sh.gather_output:
-            out = self._gather(out, rows[0], P)
-        return out
+            pred = self._gather(pred, rows[0], P)
+        return pred
 
     def capture(self, batch: Batch) -> "GraphedStep":
         """Capture one step on (a private copy of) `batch` into a hipGraph; see GraphedStep."""
@@ -582,6 +628,8 @@ class Engine:
         Fourier encoding (encoder.py:359-363) and, for dynamic-variable models, the six time-of-day /
         day-of-week / day-of-year planes (encoder.py:226-246).  They live in persistent buffers that are
         refreshed from the host BEFORE the step; a captured hipGraph only reads them."""
+        if self.native is not None and not self._capturing and self.native._grid_key is not None:
+            self.native.set_time(times)
         D = self.cfg.embed_dim
         bufs = self._time_bufs.get(B)
         if bufs is None:
@@ -879,15 +927,19 @@ class Engine:
                     lib.linear(a_in, w_qkv, blk["qkv.b"], qkv[:Ls])
                     ao = self.empty(M, dim, dtype=T_)
                     if pl["send"] or pl["recv"]:
-                        # halo rows travel while the windows that need none of them are attended
-                        sends = [(q, lib.gather_rows(qkv[:Ls], idx, self.empty(idx.numel(), 3 * dim, dtype=T_)))
+                        # Halo rows travel while the windows that need none of them are attended.  A halo row is only
+                        # ever a key / value (its own rank computes its queries), so the k | v columns travel, not q:
+                        # two thirds of the bytes.
+                        sends = [(q, lib.gather_rows(qkv[:Ls, dim:], idx, self.empty(idx.numel(), 2 * dim, dtype=T_)))
                                  for q, idx in pl["send"].items()]
-                        recvs = [(q, qkv[Ls + off:Ls + off + cnt]) for q, (off, cnt) in pl["recv"].items()]
-                        yield Exchange(sends, recvs, deferred=True)
+                        landing = {q: self.empty(cnt, 2 * dim, dtype=T_) for q, (off, cnt) in pl["recv"].items()}
+                        yield Exchange(sends, list(landing.items()), deferred=True)
                         if pl["interior"] is not None:
                             lib.window_attention(qkv, blk["qkv.b"], ao, *pl["interior"], B, Ls + pl["n_halo"], dim, heads,
                                                  L_out=Ls)
                         yield Complete()
+                        for q, (off, cnt) in pl["recv"].items():
+                            lib.copy2d(landing[q], qkv[Ls + off:Ls + off + cnt, dim:])
                         if pl["boundary"] is not None:
                             lib.window_attention(qkv, blk["qkv.b"], ao, *pl["boundary"], B, Ls + pl["n_halo"], dim, heads,
                                                  L_out=Ls)
@@ -984,7 +1036,16 @@ class Engine:
         return x_cat
 
     # -- decoder ------------------------------------------------------------------------------
-    def _decode(self, x_cat, batch: Batch, B, H, W, Hp, Wp, levels) -> Batch:
+    @staticmethod
+    def _dest(out, kind: int, name: str, shape, device) -> torch.Tensor:
+        """The caller's destination tensor for a predicted variable if it is usable as is, else a fresh one."""
+        t = None if out is None else out[kind].get(name)
+        if (t is not None and tuple(t.shape) == tuple(shape) and t.dtype == F32 and t.is_contiguous()
+                and t.device == device):
+            return t
+        return torch.empty(shape, dtype=F32, device=device)
+
+    def _decode(self, x_cat, batch: Batch, B, H, W, Hp, Wp, levels, out=None) -> Batch:
         cfg, model = self.cfg, self.model
         P, D2 = cfg.patch_size, 2 * cfg.embed_dim
         L, Cl, CA = Hp * Wp, cfg.latent_levels, len(levels)
@@ -1014,7 +1075,7 @@ class Engine:
         y_s = self.empty(B * L, ld_s)
         for b in range(B):
             lib.linear(x_cat[b * Cl * L:b * Cl * L + L], w_sh, b_sh, y_s[b * L:(b + 1) * L], n=n_s)
-        out_s = self.empty(len(surf_in), B, 1, H, W)
+        out_s = [self._dest(out, 0, n, (B, 1, H, W), self.device) for n in surf_in]
         descs = []
         for i, n in enumerate(surf_in):
             loc, sc, _ = self._stats("surf", n, levels)
@@ -1046,7 +1107,7 @@ class Engine:
         groups = {"main": [n for n in atmos_heads if n not in sep]}
         if sep:
             groups["alt"] = [n for n in atmos_heads if n in sep]
-        out_a = self.empty(len(atmos_in), B, CA, H, W)
+        out_a = [self._dest(out, 1, n, (B, 1, CA, H, W), self.device) for n in atmos_in]
         for gname, names in groups.items():
             if not names:
                 continue
@@ -1076,7 +1137,7 @@ class Engine:
             self._keep_y = y_a
 
         surf_out = {n: out_s[i] for i, n in enumerate(surf_in)}               # (B, 1, H, W)
-        atmos_out = {n: out_a[i][:, None] for i, n in enumerate(atmos_in)}    # (B, 1, C, H, W)
+        atmos_out = {n: out_a[i] for i, n in enumerate(atmos_in)}             # (B, 1, C, H, W)
         new_md = derive_metadata(md, lat=md.lat.to(F32), lon=md.lon.to(F32),
                                  time=tuple(t + cfg.timestep for t in md.time), rollout_step=new_step)
         if self._cur_band is not None:
@@ -1151,16 +1212,15 @@ class GraphedStep:
         try:
             with torch.cuda.graph(self.graph):
                 self.pred = engine.step(self.state)
-                for k, v in self.pred.surf_vars.items():     # history shift, inside the graph
-                    x = self.state.surf_vars[k]
-                    if x.shape[1] > 1:
-                        x[:, :-1].copy_(x[:, 1:].clone())
-                    x[:, -1:].copy_(v)
-                for k, v in self.pred.atmos_vars.items():
-                    x = self.state.atmos_vars[k]
-                    if x.shape[1] > 1:
-                        x[:, :-1].copy_(x[:, 1:].clone())
-                    x[:, -1:].copy_(v)
+                # History shift, inside the graph: the captured step reads fixed addresses, so the states move, not the
+                # window (slot t <- slot t+1 in ascending order: no temporary; then the prediction into the last slot).
+                for preds, states in ((self.pred.surf_vars, self.state.surf_vars),
+                                      (self.pred.atmos_vars, self.state.atmos_vars)):
+                    for k, v in preds.items():
+                        x = states[k]
+                        for t in range(x.shape[1] - 1):
+                            x[:, t].copy_(x[:, t + 1])
+                        x[:, -1:].copy_(v)
         finally:
             engine._capturing = False
 

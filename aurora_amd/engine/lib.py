@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from ctypes import c_float, c_int, c_int32, c_int64, c_void_p
 from pathlib import Path
 from typing import Optional
@@ -49,8 +50,10 @@ def unpatch_var(dst: int, loc: int, scale: int, clamp_min0: int, col0: int) -> U
 _SIGNATURES = {
     "aurora_hip_version": (c_int, []),
     "aurora_hip_last_error": (ctypes.c_char_p, []),
-    "aurora_hip_set_f32_gemm": (c_int, [c_int]),
-    "aurora_hip_set_f32_guard": (c_int, [c_void_p, ctypes.c_float]),
+    "aurora_hip_default_f32_gemm": (c_int, []),
+    "aurora_hip_linear_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                     c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                     c_int, c_int, c_void_p, c_float, c_void_p]),
     "aurora_hip_absmax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "aurora_hip_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
@@ -196,10 +199,35 @@ class _Timed:
 
 
 # ---- wrappers ------------------------------------------------------------------------------
-def set_f32_gemm(mode: int) -> int:
-    """0 = native fp32 MFMA, 1 = exact 3 x bf16 operand splitting (default), 2 = 2 x fp16 splitting (bounded
-    activations only); returns the previous mode."""
-    return load().aurora_hip_set_f32_gemm(mode)
+# How fp32 linears issued by THIS thread are multiplied: (mode, guard tensor, guard limit); mode -1 = process default.
+# Passed per call to aurora_hip_linear_ex -- the library itself keeps no mutable state, so two engines on different
+# threads / streams cannot disturb each other, and nothing hidden is baked into a captured graph.
+_f32 = threading.local()
+
+
+def _f32_state():
+    return getattr(_f32, "state", (-1, None, 0.0))
+
+
+def default_f32_gemm() -> int:
+    """The process default (AURORA_F32_GEMM=native|bf16|f16): 0 native fp32 MFMA, 1 three bf16 terms, 2 two fp16 terms."""
+    return load().aurora_hip_default_f32_gemm()
+
+
+class f32_gemm:
+    """`with f32_gemm(mode):` -- fp32 linears issued by this thread inside use `mode` (0 native fp32 MFMA, 1 exact
+    3 x bf16 operand splitting, 2 2 x fp16 splitting)."""
+
+    def __init__(self, mode: int, guard=None):
+        self.state = (mode, None if guard is None else guard[0], 0.0 if guard is None else float(guard[1]))
+
+    def __enter__(self):
+        self.prev = _f32_state()
+        _f32.state = self.state
+
+    def __exit__(self, *exc):
+        _f32.state = self.prev
+        return False
 
 
 def absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -211,30 +239,22 @@ def absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     return out
 
 
-class bounded_activations:
+class bounded_activations(f32_gemm):
     """`with bounded_activations():` -- the fp32 linears issued inside may use the 2 x fp16 operand split (three
     MFMAs instead of six, the same 2^-24 operand accuracy).  Without arguments the caller vouches that their
     activation operand is bounded by construction -- a LayerNorm output or the GELU of a linear of one -- i.e. far
     inside fp16's range (|x| < 65504) whatever the model's inputs are.  With `guard=(amax, limit)` the decision is
     taken on the device, per launch: fp16 terms iff `amax[0] < limit` (`amax` from `absmax`, or a bound derived from
-    it), three bf16 terms otherwise.  Honours an explicit native / bf16 choice made through AURORA_F32_GEMM or
-    `set_f32_gemm(0)`."""
+    it), three bf16 terms otherwise.  Honours an explicit native / bf16 choice made through AURORA_F32_GEMM or an
+    enclosing `f32_gemm(0)`."""
 
     def __init__(self, guard=None):
-        self.guard = guard
+        super().__init__(2, guard)
 
     def __enter__(self):
-        self.prev = set_f32_gemm(-1)
-        if self.prev == 1 and os.environ.get("AURORA_F32_GEMM") is None:
-            set_f32_gemm(2)
-            if self.guard is not None:
-                load().aurora_hip_set_f32_guard(_ptr(self.guard[0]), float(self.guard[1]))
-
-    def __exit__(self, *exc):
-        if self.guard is not None:
-            load().aurora_hip_set_f32_guard(None, 0.0)
-        set_f32_gemm(self.prev)
-        return False
+        self.prev = _f32_state()
+        explicit = self.prev[0] >= 0 or os.environ.get("AURORA_F32_GEMM") is not None
+        _f32.state = self.prev if explicit else self.state
 
 
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
@@ -259,9 +279,10 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
         ldr, _ = _rows(residual)
     name = "linear_bf16" if a.dtype == torch.bfloat16 else "linear_f32"
     with _Timed(name, 2.0 * M * N * K):  # algorithmic FLOPs
-        _check(load().aurora_hip_linear(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), _ptr(out), ldc, _ptr(out2),
-                                        ldc2, _ptr(residual), ldr, M, N, K, dtype_code(a.dtype), act,
-                                        _stream()))
+        mode, guard, limit = _f32_state()
+        _check(load().aurora_hip_linear_ex(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), _ptr(out), ldc, _ptr(out2),
+                                           ldc2, _ptr(residual), ldr, M, N, K, dtype_code(a.dtype), act,
+                                           mode, _ptr(guard), limit, _stream()))
     return out
 
 
@@ -403,3 +424,57 @@ def convert(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
     with _Timed("convert", 0.0):
         _check(load().aurora_hip_convert(_ptr(src), _ptr(dst), src.numel(), dtype_code(src.dtype), _stream()))
     return dst
+
+
+# ---- model handle (one forecast step behind the C ABI) ------------------------------------------------------
+class HipConfig(ctypes.Structure):
+    _fields_ = [("embed_dim", c_int32), ("patch_size", c_int32), ("latent_levels", c_int32), ("num_heads", c_int32),
+                ("n_stages", c_int32), ("encoder_depths", c_int32 * 4), ("encoder_heads", c_int32 * 4),
+                ("decoder_depths", c_int32 * 4), ("decoder_heads", c_int32 * 4), ("window", c_int32 * 3),
+                ("enc_depth", c_int32), ("dec_depth", c_int32), ("perceiver_ln_eps", c_float),
+                ("max_history", c_int32), ("timestep_hours", ctypes.c_double), ("stabilise_level_agg", c_int32),
+                ("use_lora", c_int32), ("lora_steps", c_int32), ("lora_mode", c_int32), ("autocast", c_int32),
+                ("n_surf", c_int32), ("n_static", c_int32), ("n_atmos", c_int32),
+                ("surf_vars", ctypes.POINTER(ctypes.c_char_p)), ("static_vars", ctypes.POINTER(ctypes.c_char_p)),
+                ("atmos_vars", ctypes.POINTER(ctypes.c_char_p))]
+
+
+_PD = ctypes.POINTER(ctypes.c_double)
+_PF = ctypes.POINTER(ctypes.c_float)
+
+
+class HipGrid(ctypes.Structure):
+    _fields_ = [("n_lat", c_int32), ("n_lon", c_int32), ("lat", _PD), ("lon", _PD), ("n_levels", c_int32),
+                ("levels", _PD), ("levels_float32", c_int32), ("surf_loc", _PD), ("surf_scale", _PD),
+                ("static_loc", _PD), ("static_scale", _PD), ("atmos_loc", _PD), ("atmos_scale", _PD),
+                ("pos_encoding", _PF), ("scale_encoding", _PF)]
+
+
+class HipStepIO(ctypes.Structure):
+    _fields_ = [("B", c_int32), ("T", c_int32), ("surf", ctypes.POINTER(c_void_p)), ("surf_strides", c_int64 * 4),
+                ("stat", ctypes.POINTER(c_void_p)), ("static_strides", c_int64 * 2),
+                ("atmos", ctypes.POINTER(c_void_p)), ("atmos_strides", c_int64 * 5),
+                ("out_surf", ctypes.POINTER(c_void_p)), ("out_atmos", ctypes.POINTER(c_void_p)),
+                ("rollout_step", c_int32)]
+
+
+class HipProfileEntry(ctypes.Structure):
+    _fields_ = [("kernel", ctypes.c_char_p), ("launches", c_int64), ("ms", ctypes.c_double), ("work", ctypes.c_double)]
+
+
+PROFILE_KINDS = ("linear_bf16", "linear_f32", "window_attention_bf16", "layernorm", "merge_ln", "split_ln", "patchify",
+                 "perceiver_attention", "assemble_tokens", "unpatchify", "copy2d", "absmax")
+
+_SIGNATURES.update({
+    "aurora_hip_profile_begin": (c_int, [c_void_p, ctypes.c_uint32]),
+    "aurora_hip_profile_end": (c_int, [c_void_p, ctypes.POINTER(HipProfileEntry), c_int, ctypes.POINTER(c_int)]),
+    "aurora_hip_create": (c_int, [ctypes.POINTER(HipConfig), ctypes.POINTER(c_void_p)]),
+    "aurora_hip_destroy": (None, [c_void_p]),
+    "aurora_hip_pack_weights": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.POINTER(c_int64), c_int, c_int, c_int]),
+    "aurora_hip_finalize": (c_int, [c_void_p, c_void_p]),
+    "aurora_hip_precompute": (c_int, [c_void_p, ctypes.POINTER(HipGrid), c_void_p]),
+    "aurora_hip_set_time": (c_int, [c_void_p, _PD, c_int, c_void_p]),
+    "aurora_hip_step": (c_int, [c_void_p, ctypes.POINTER(HipStepIO), c_void_p]),
+    "aurora_hip_workspace_bytes": (c_int64, [c_void_p]),
+})
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)

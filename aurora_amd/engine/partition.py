@@ -12,8 +12,12 @@ table, a band needs no special kernel: its table indexes a local buffer `[own ro
 the halo rows are received from the neighbouring ranks, and outputs are written for owned tokens
 only.  Windows that straddle a boundary are evaluated on both sides (each for its own queries).
 
-The cyclic wrap of the latitude roll (last rows <-> first rows) is part of the global table and is
-handled like any other foreign token; the -100 mask separates those groups exactly as upstream.
+Foreign tokens that no owned query can see are not exchanged at all: in a shifted block the -100 mask
+(swin3d.py:333-358) only lets tokens of the same group attend to each other, so a foreign position whose group
+contains no owned position of that window is replaced by an absent one (token -1, its group label kept: it stays
+masked, with weight exp(-100) ~ 4e-44 instead of a real key's exp(-100 + ...)).  This is what makes the cyclic wrap
+of the latitude roll free: the window row that holds the last three and -- rolled -- the first
+three latitude rows puts them in different groups, so the first and the last rank never talk to each other.
 
 Everything here is host-side numpy, derived from `geometry.window_tables` (which is itself checked
 against the reference's roll/pad/partition chain).  tests/test_partition.py replays the plans with
@@ -102,8 +106,15 @@ def block_plans(res: Res, window: Res, shifted: bool, rows: tuple[tuple[int, int
     plans = []
     for r, (h0, h1) in enumerate(rows):
         mine = (owner == r).any(axis=1)                      # windows touching the band
-        tw, ow = tok_g[mine], owner[mine]
+        tw, ow = tok_g[mine].copy(), owner[mine].copy()
         gw = None if grp_g is None else np.ascontiguousarray(grp_g[mine])
+        if gw is not None:
+            # drop the foreign positions whose mask group holds no owned position of the same window
+            bits = np.bitwise_or.reduce(np.where(ow == r, np.uint32(1) << gw.astype(np.uint32), np.uint32(0)), axis=1)
+            visible = ((bits[:, None] >> gw.astype(np.uint32)) & 1).astype(bool)
+            unseen = (ow != r) & (ow >= 0) & ~visible
+            tw[unseen] = -1
+            ow[unseen] = -1
         foreign = np.unique(tw[(ow != r) & (ow >= 0)])       # sorted global ids
         f_owner = owner_of_row[(foreign // W) % H]
         order = np.lexsort((foreign, f_owner))               # group by owning rank, then by id

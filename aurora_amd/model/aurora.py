@@ -174,9 +174,13 @@ class Aurora(nn.Module):
         self._shard = None   # see configure_sharding()
 
     # -- the step ------------------------------------------------------------------------
-    def forward(self, batch: Batch) -> Batch:
-        """One forecast step: `batch` (history of T states) -> prediction at +timestep."""
-        return self.engine().step(batch)
+    def forward(self, batch: Batch, out=None) -> Batch:
+        """One forecast step: `batch` (history of T states) -> prediction at +timestep.
+
+        `out` (not in the reference; used by `rollout`): `(surf, atmos)` dictionaries of preallocated float32 device
+        tensors, `(B, 1, H, W)` / `(B, 1, C, H, W)` per variable.  Where such a tensor is contiguous the prediction is
+        written into it directly; the returned Batch then holds exactly that tensor."""
+        return self.engine().step(batch, out=out)
 
     def engine(self):
         """The HIP engine bound to this model (created and weight-packed on first use)."""

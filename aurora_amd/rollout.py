@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import dataclasses
+from collections import deque
 from typing import Generator
 
 import torch
@@ -11,8 +12,44 @@ from aurora_amd.batch import Batch
 
 __all__ = ["rollout"]
 
+_RING = 8   # history states per ring chunk
 
-def rollout(model, batch: Batch, steps: int, graph: bool = False) -> Generator[Batch, None, None]:
+
+class _History:
+    """The history of one variable, (B, T, ...) per step, WITHOUT the reference's per-step `torch.cat`
+    (aurora/rollout.py:39-49: `cat([old[:, 1:], pred], dim=1)` re-copies the T-1 surviving states of every variable at
+    every step).  States live in a chunk (B, R, ...) along the history axis; the window handed to the model is the view
+    chunk[:, i:i+T], a prediction is written into slot i+T and the window slides by one -- no copy.  When a chunk is
+    full a fresh one is allocated and seeded with the T-1 newest states (one copy per R-T+1 steps); finished chunks are
+    never overwritten, so predictions handed to the caller (views into them) stay valid for as long as they are held."""
+
+    def __init__(self, x: torch.Tensor) -> None:
+        self.T = x.shape[1]
+        self.chunk = x.new_empty((x.shape[0], max(_RING, self.T + 1), *x.shape[2:]))
+        self.chunk[:, :self.T].copy_(x)
+        self.i = 0
+
+    def window(self) -> torch.Tensor:
+        return self.chunk[:, self.i:self.i + self.T]
+
+    def slot(self) -> torch.Tensor:
+        """Where the next prediction (B, 1, ...) goes.  The model writes it there itself when it can (`out=`)."""
+        T, R = self.T, self.chunk.shape[1]
+        self._fresh = None
+        if self.i + T == R:   # chunk full: continue in a new one, seeded with the T-1 states that stay in the window
+            self._fresh = torch.empty_like(self.chunk)
+            self._fresh[:, :T - 1].copy_(self.chunk[:, self.i + 1:])
+            return self._fresh[:, T - 1:T]
+        return self.chunk[:, self.i + T:self.i + T + 1]
+
+    def advance(self) -> None:
+        if self._fresh is not None:
+            self.chunk, self.i, self._fresh = self._fresh, 0, None
+        else:
+            self.i += 1
+
+
+def rollout(model, batch: Batch, steps: int, graph: bool = False, to_host: bool = False) -> Generator[Batch, None, None]:
     """Yield `steps` successive predictions, feeding each one back as the newest history state.
 
     The batch is brought to the model's dtype/device once; every prediction stays on the
@@ -21,7 +58,15 @@ def rollout(model, batch: Batch, steps: int, graph: bool = False) -> Generator[B
     `graph=True` (not in the reference) captures the step as a hipGraph after a warm-up step and
     replays it: one host call per step instead of ~750 kernel launches; the history is shifted inside
     the graph.  A new graph is captured whenever the LoRA weight set / clamping phase of the step changes.
+
+    `to_host=True` (not in the reference) yields the predictions in pinned HOST memory instead: the device->host
+    copy of step s (286 MB at 0.25 degree) runs on a side stream while step s+1 computes, so the caller's
+    `[p.to("cpu") for p in rollout(...)]` pattern costs no step time.  Predictions arrive one step late (the generator
+    runs one step ahead); nothing else changes.
     """
+    if to_host:
+        yield from _to_host(rollout(model, batch, steps, graph=graph))
+        return
     if graph:
         yield from _rollout_graphed(model, batch, steps)
         return
@@ -33,21 +78,60 @@ def rollout(model, batch: Batch, steps: int, graph: bool = False) -> Generator[B
         # sharded model that keeps its state distributed: continue from this rank's latitude band
         batch = model.engine().local_band(batch)
 
+    hist_s = {k: _History(v) for k, v in batch.surf_vars.items()}
+    hist_a = {k: _History(v) for k, v in batch.atmos_vars.items()}
     for _ in range(steps):
-        pred = model.forward(batch)
+        # Newest state in, oldest state out -- by sliding a window over the history chunks: the model writes its
+        # prediction straight into the next slot (no copy at all) when that slot is a plain contiguous field (B = 1),
+        # otherwise the prediction is copied in.  `pred` carries time and rollout_step.
+        slots = ({k: h.slot() for k, h in hist_s.items()}, {k: h.slot() for k, h in hist_a.items()})
+        pred = model.forward(batch, out=slots)
+        surf, atmos = {}, {}
+        for hist, src, dst in ((hist_s, pred.surf_vars, surf), (hist_a, pred.atmos_vars, atmos)):
+            for k, v in src.items():
+                slot = slots[0 if hist is hist_s else 1][k]
+                if v.data_ptr() != slot.data_ptr():
+                    slot.copy_(v)
+                hist[k].advance()
+                dst[k] = slot
+        pred = dataclasses.replace(pred, surf_vars=surf, atmos_vars=atmos)
         yield pred
-        # Newest state in, oldest state out.  `pred` carries time and rollout_step.
         batch = dataclasses.replace(
             pred,
-            surf_vars={
-                k: torch.cat([batch.surf_vars[k][:, 1:], v], dim=1)
-                for k, v in pred.surf_vars.items()
-            },
-            atmos_vars={
-                k: torch.cat([batch.atmos_vars[k][:, 1:], v], dim=1)
-                for k, v in pred.atmos_vars.items()
-            },
+            surf_vars={k: hist_s[k].window() for k in pred.surf_vars},
+            atmos_vars={k: hist_a[k].window() for k in pred.atmos_vars},
         )
+
+
+def _to_host(preds) -> Generator[Batch, None, None]:
+    """Device predictions -> pinned host memory, asynchronously, one step behind the computation."""
+    side = torch.cuda.Stream()
+    pending: deque = deque()
+
+    def finish(item):
+        host, done, _keep = item
+        done.synchronize()
+        return host
+
+    for pred in preds:
+        ready = torch.cuda.Event()
+        ready.record()                       # the step's kernels are enqueued on the current stream
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            pin = lambda v: torch.empty(v.shape, dtype=v.dtype, pin_memory=True).copy_(v, non_blocking=True)  # noqa: E731
+            host = dataclasses.replace(
+                pred,
+                surf_vars={k: pin(v) for k, v in pred.surf_vars.items()},
+                static_vars={k: v for k, v in pred.static_vars.items()},
+                atmos_vars={k: pin(v) for k, v in pred.atmos_vars.items()},
+            )
+            done = torch.cuda.Event()
+            done.record(side)
+        pending.append((host, done, pred))   # `pred` stays referenced until its copy has finished
+        if len(pending) > 1:
+            yield finish(pending.popleft())
+    while pending:
+        yield finish(pending.popleft())
 
 
 def _rollout_graphed(model, batch: Batch, steps: int) -> Generator[Batch, None, None]:

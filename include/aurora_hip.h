@@ -53,25 +53,28 @@ int aurora_hip_linear(const void* A, int64_t lda, const void* W, int64_t ldw, co
                       const float* residual, int64_t ldr,
                       int64_t M, int N, int K, int dtype, int act, void* stream);
 
-/* How large fp32 linears (N % 256 == 0) are multiplied.
+/* aurora_hip_linear with the fp32 numerics chosen PER CALL (the library keeps no mutable state):
+ * f32_gemm says how a large fp32 linear (N % 256 == 0) is multiplied; -1 takes the process default.
  *   1 (default): every fp32 operand is split exactly into three bf16 terms and six bf16 MFMAs per K-slab
  *      reproduce the fp32 product to ~1e-7 relative (fp32-grade, no range restriction, 16/6 of the fp32 MFMA rate).
  *   2: two fp16 terms (round-to-nearest: a_h + a_l = a to 2^-24 |a|), three fp16 MFMAs, the weight operand scaled
  *      by 2^6 and the result scaled back exactly.  Same accuracy, but inside fp16's range only: activations must
- *      satisfy |x| < 65504 (|x| < 0.25 carries an absolute error of up to 3e-8), weights |w| < 1000.  Meant to be
- *      switched on around linears whose input is bounded by construction (a LayerNorm output, the GELU of a
- *      linear of one), whatever the model inputs are.
- *   0: native v_mfma_f32_16x16x4_f32 FMA chains.
- * The environment variable AURORA_F32_GEMM=native|bf16|f16 sets the initial mode.  Returns the previous mode; any
- * other argument only queries.  The reference's counterpart is the fp32 F.linear outside autocast
+ *      satisfy |x| < 65504 (|x| < 0.25 carries an absolute error of up to 3e-8), weights |w| < 1000.  Meant for
+ *      linears whose input is bounded by construction (a LayerNorm output, the GELU of a linear of one), whatever
+ *      the model inputs are.  With `guard` != NULL the decision is taken on the device, per launch: the two-term
+ *      split runs only if *guard < guard_limit, else the three-term bf16 split -- the caller leaves max |activation|
+ *      (or an upper bound of it, scaled into guard_limit) there, e.g. with aurora_hip_absmax, without any host
+ *      synchronisation.
+ *   0: native v_mfma_f32_16x16x4_f32 FMA chains (bitwise an fp32 FMA chain; erff in the GELU epilogue).
+ * The environment variable AURORA_F32_GEMM=native|bf16|f16 sets the process default, which
+ * aurora_hip_default_f32_gemm() reports.  The reference's counterpart is the fp32 F.linear outside autocast
  * (encoder.py / decoder.py, aurora.py:322-349). */
-int aurora_hip_set_f32_gemm(int mode);
-
-/* Range guard for mode 2: while `device_absmax` is non-null, large fp32 linears issued in mode 2 read that device word
- * at run time and use the two-term fp16 split only if *device_absmax < limit (else the three-term bf16 split): the
- * caller leaves max |activation| -- or an upper bound of it, scaled into `limit` -- there, e.g. with
- * aurora_hip_absmax, without any host synchronisation.  NULL removes the guard. */
-int aurora_hip_set_f32_guard(const float* device_absmax, float limit);
+int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                         void* C, int64_t ldc, void* C2, int64_t ldc2,
+                         const float* residual, int64_t ldr,
+                         int64_t M, int N, int K, int dtype, int act,
+                         int f32_gemm, const float* guard, float guard_limit, void* stream);
+int aurora_hip_default_f32_gemm(void);
 
 /* out[0] = max |x[i]| over n contiguous fp32 values (x 16-byte aligned); NaNs are ignored. */
 int aurora_hip_absmax(const float* x, int64_t n, float* out, void* stream);
@@ -226,6 +229,107 @@ int aurora_hip_gather_rows(const void* src, int64_t src_pitch_bytes, const int32
                            int64_t dst_pitch_bytes, int64_t n_rows, int64_t row_bytes, void* stream);
 /* dst (other dtype) = convert(src): n elements, fp32 -> bf16 (round-nearest-even) or back. */
 int aurora_hip_convert(const void* src, void* dst, int64_t n, int src_dtype, void* stream);
+
+/* =============================================================================================
+ * Model handle: ONE FORECAST STEP behind the C ABI.
+ *
+ * Replaces `Aurora.forward` (aurora/model/aurora.py:265-392) = Perceiver3DEncoder.forward (encoder.py:198-366) +
+ * Swin3DTransformerBackbone.forward (swin3d.py:884-936) + Perceiver3DDecoder.forward (decoder.py:168-276) with the
+ * normalisation of Batch.normalise / unnormalise (batch.py:94-140) fused in, for the ERA5 model family (Aurora,
+ * AuroraPretrained, AuroraSmallPretrained, Aurora12hPretrained, AuroraHighRes).  Call order:
+ *
+ *   aurora_hip_create(&config, &model)
+ *   aurora_hip_pack_weights(model, name, data, shape, ndim, AURORA_F32, on_device)   for every state_dict entry, after the
+ *                                       checkpoint adapters (compat.py) -- names and shapes are the reference's schema
+ *   aurora_hip_finalize(model, stream)          bf16 backbone copies, AdaLN modulation, fused heads, base weight set
+ *   aurora_hip_precompute(model, &grid, stream) per grid / level set: Fourier tables, window tables, statistics
+ *   per step:  aurora_hip_set_time(model, hours, B, stream);  aurora_hip_step(model, &io, stream)
+ *   aurora_hip_destroy(model)
+ *
+ * Everything is enqueued on `stream`; a step performs no host synchronisation and may be captured into a hipGraph once
+ * one step has run eagerly (the workspace grows on the first step; aurora_hip_set_time stays outside the capture).
+ * One in-flight step per handle (the reference's own threading contract, foundry/server/mlflow_wrapper.py:121).
+ * The library keeps no state outside the handles.
+ */
+typedef struct aurora_hip_model aurora_hip_model;
+
+typedef struct aurora_hip_config {   /* Aurora.__init__ keywords, aurora/model/aurora.py:55-95 */
+  int32_t embed_dim, patch_size, latent_levels, num_heads;   /* num_heads: heads of the Perceivers */
+  int32_t n_stages;                                          /* len(encoder_depths), <= 4 */
+  int32_t encoder_depths[4], encoder_heads[4], decoder_depths[4], decoder_heads[4];
+  int32_t window[3];
+  int32_t enc_depth, dec_depth;
+  float perceiver_ln_eps;
+  int32_t max_history;
+  double timestep_hours;
+  int32_t stabilise_level_agg, use_lora, lora_steps, lora_mode;   /* lora_mode: 0 single, 1 from_second, 2 all */
+  int32_t autocast;                                          /* 1: bf16 backbone (aurora.py:327-343) */
+  int32_t n_surf, n_static, n_atmos;
+  const char* const* surf_vars;                              /* fixes the order of every per-variable array below */
+  const char* const* static_vars;
+  const char* const* atmos_vars;
+} aurora_hip_config;
+
+typedef struct aurora_hip_grid {     /* HOST pointers */
+  int32_t n_lat, n_lon;              /* of the data; one surplus latitude row (n_lat % patch == 1) is dropped, batch.py:142-168 */
+  const double* lat;                 /* [n_lat] degrees, decreasing */
+  const double* lon;                 /* [n_lon] degrees */
+  int32_t n_levels;
+  const double* levels;              /* [n_levels] hPa */
+  int32_t levels_float32;            /* 1: the levels pass through float32 (a tuple containing a float upstream) */
+  const double* surf_loc;            /* normalisation statistics (aurora/normalisation.py): [n_surf] */
+  const double* surf_scale;
+  const double* static_loc;          /* [n_static] */
+  const double* static_scale;
+  const double* atmos_loc;           /* [n_atmos][n_levels] */
+  const double* atmos_scale;
+  /* Optional (both or neither): the Fourier position / scale features of the patch grid, [L][embed_dim] each, L = patches
+   * per level.  The reference derives them from lat / lon in float32 torch kernels whose last-ulp behaviour the expansion
+   * amplifies (wavelengths down to 1e-4 km); a caller that must reproduce a particular host's numbers bit for bit
+   * supplies them, otherwise they are computed here (float32 geometry as upstream, fp64 trigonometry). */
+  const float* pos_encoding;
+  const float* scale_encoding;
+} aurora_hip_grid;
+
+typedef struct aurora_hip_step_io {  /* DEVICE pointers; variable order = the config's */
+  int32_t B, T;                      /* batch size, history states given (<= max_history) */
+  const float* const* surf;          /* [n_surf]   each (B, T, n_lat, n_lon) with element strides surf_strides */
+  int64_t surf_strides[4];
+  const float* const* stat;          /* [n_static] each (n_lat, n_lon) with element strides static_strides */
+  int64_t static_strides[2];
+  const float* const* atmos;         /* [n_atmos]  each (B, T, n_levels, n_lat, n_lon) with element strides atmos_strides */
+  int64_t atmos_strides[5];
+  float* const* out_surf;            /* [n_surf]   each (B, H', n_lon) contiguous, H' = n_lat - n_lat % patch */
+  float* const* out_atmos;           /* [n_atmos]  each (B, n_levels, H', n_lon) contiguous */
+  int32_t rollout_step;              /* Metadata.rollout_step of the input: selects the LoRA weight set (lora.py:105-129) */
+} aurora_hip_step_io;
+
+int aurora_hip_create(const aurora_hip_config* config, aurora_hip_model** out);
+void aurora_hip_destroy(aurora_hip_model* model);
+/* One state_dict entry (float32; `data` on the host, or on the device if on_device != 0).  The handle keeps its own copy. */
+int aurora_hip_pack_weights(aurora_hip_model* model, const char* name, const void* data, const int64_t* shape, int ndim,
+                            int dtype, int on_device);
+int aurora_hip_finalize(aurora_hip_model* model, void* stream);
+int aurora_hip_precompute(aurora_hip_model* model, const aurora_hip_grid* grid, void* stream);
+/* Absolute times of the batch elements in hours since the Unix epoch (encoder.py:359-363), host pointer. */
+int aurora_hip_set_time(aurora_hip_model* model, const double* time_hours, int B, void* stream);
+int aurora_hip_step(aurora_hip_model* model, const aurora_hip_step_io* io, void* stream);
+int64_t aurora_hip_workspace_bytes(const aurora_hip_model* model);
+
+/* Per-launch timing of the handle's own kernels: between _begin and _end every launch of a kernel kind whose bit is set
+ * in kind_mask (bit i = entry i of the table _end returns: linear_bf16, linear_f32, window_attention_bf16, layernorm,
+ * merge_ln, split_ln, patchify, perceiver_attention, assemble_tokens, unpatchify, copy2d, absmax) is bracketed by a HIP
+ * event pair on the launch stream.  _end synchronises the device and fills `out` (capacity >= 12): launches, summed
+ * milliseconds and summed algorithmic work (FLOPs for the linears, bytes for the window attention) per kind.  This is
+ * what bench.py's `roofline` is computed from.  An event pair keeps a launch from overlapping its neighbours. */
+typedef struct aurora_hip_profile_entry {
+  const char* kernel;
+  int64_t launches;
+  double ms;
+  double work;
+} aurora_hip_profile_entry;
+int aurora_hip_profile_begin(aurora_hip_model* model, uint32_t kind_mask);
+int aurora_hip_profile_end(aurora_hip_model* model, aurora_hip_profile_entry* out, int capacity, int* n_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,168 @@
+"""A forecast through the C ABI alone: create / pack_weights / finalize / precompute / set_time / step driven with
+ctypes, numpy host arrays and raw device pointers -- no `Engine`, no `aurora_amd.Aurora.forward`, no Python
+sequencing.  torch appears only as the device allocator (and for the history shift between roll-out steps, which is the
+caller's job exactly as in aurora/rollout.py:39-49).  The predictions must match the reference goldens to the same
+tolerance as the Python-facing API (tests/test_gpu_model.py): mean-rel <= 1e-4 per variable.
+
+The handle computes the Fourier position / scale tables itself here (lat / lon passed, no tables): the C++ restatement of
+posencoding.py:61-192 is what is being checked.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import aurora_amd
+from aurora_amd import normalisation
+from aurora_amd.engine import lib
+from tests import helpers
+from tests.golden_cases import CASES
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+_MODES = {"single": 0, "from_second": 1, "all": 2}
+
+
+def _carr(ctype, values):
+    return (ctype * max(len(values), 1))(*values)
+
+
+class Handle:
+    """The binding a maintainer of another host language would write, in ctypes."""
+
+    def __init__(self, cfg, autocast, state_dict):
+        self.L = lib.load()
+        self.cfg = cfg
+        c = lib.HipConfig()
+        c.embed_dim, c.patch_size, c.latent_levels, c.num_heads = cfg.embed_dim, cfg.patch_size, cfg.latent_levels, cfg.num_heads
+        c.n_stages = len(cfg.encoder_depths)
+        for i in range(c.n_stages):
+            c.encoder_depths[i], c.encoder_heads[i] = cfg.encoder_depths[i], cfg.encoder_num_heads[i]
+            c.decoder_depths[i], c.decoder_heads[i] = cfg.decoder_depths[i], cfg.decoder_num_heads[i]
+        for i in range(3):
+            c.window[i] = cfg.window_size[i]
+        c.enc_depth, c.dec_depth, c.perceiver_ln_eps = cfg.enc_depth, cfg.dec_depth, cfg.perceiver_ln_eps
+        c.max_history, c.timestep_hours = cfg.max_history_size, cfg.timestep.total_seconds() / 3600
+        c.stabilise_level_agg, c.use_lora, c.lora_steps = int(cfg.stabilise_level_agg), int(cfg.use_lora), cfg.lora_steps
+        c.lora_mode, c.autocast = _MODES[cfg.lora_mode], int(autocast)
+        self._names = [_carr(ctypes.c_char_p, [n.encode() for n in v]) for v in (cfg.surf_vars, cfg.static_vars, cfg.atmos_vars)]
+        c.n_surf, c.n_static, c.n_atmos = len(cfg.surf_vars), len(cfg.static_vars), len(cfg.atmos_vars)
+        c.surf_vars, c.static_vars, c.atmos_vars = self._names
+        self.h = ctypes.c_void_p()
+        self.check(self.L.aurora_hip_create(ctypes.byref(c), ctypes.byref(self.h)))
+        for name, w in state_dict.items():          # HOST arrays: on_device = 0
+            w = np.ascontiguousarray(w, np.float32)
+            shape = _carr(ctypes.c_int64, list(w.shape))
+            self.check(self.L.aurora_hip_pack_weights(self.h, name.encode(), w.ctypes.data_as(ctypes.c_void_p), shape, w.ndim, 0, 0))
+        self.check(self.L.aurora_hip_finalize(self.h, None))
+
+    def check(self, code):
+        assert code == 0, self.L.aurora_hip_last_error().decode()
+
+    def precompute(self, lat, lon, levels):
+        cfg, g = self.cfg, lib.HipGrid()
+        g.n_lat, g.n_lon, g.n_levels = len(lat), len(lon), len(levels)
+        dbl = lambda v: _carr(ctypes.c_double, [float(x) for x in v])  # noqa: E731
+        sa = [normalisation.surf_affine(n) for n in cfg.surf_vars]
+        ta = [normalisation.surf_affine(n) for n in cfg.static_vars]
+        aa = [normalisation.atmos_affine(n, levels) for n in cfg.atmos_vars]
+        keep = [dbl(lat), dbl(lon), dbl(levels), dbl([a[0] for a in sa]), dbl([a[1] for a in sa]), dbl([a[0] for a in ta]),
+                dbl([a[1] for a in ta]), dbl([x for a in aa for x in a[0]]), dbl([x for a in aa for x in a[1]])]
+        (g.lat, g.lon, g.levels, g.surf_loc, g.surf_scale, g.static_loc, g.static_scale, g.atmos_loc, g.atmos_scale) = keep
+        g.levels_float32 = int(not all(isinstance(v, int) for v in levels))
+        self.check(self.L.aurora_hip_precompute(self.h, ctypes.byref(g), None))
+
+    def step(self, surf, static, atmos, times, rollout_step, levels):
+        """surf / atmos: lists of device tensors (B, T, H, W) / (B, T, C, H, W); returns lists of (B, H', W) / (B, C, H', W)."""
+        cfg = self.cfg
+        B, T, H, W = surf[0].shape
+        Hc = H - H % cfg.patch_size
+        hours = _carr(ctypes.c_double, [t.timestamp() / 3600 for t in times])
+        self.check(self.L.aurora_hip_set_time(self.h, hours, B, None))
+        out_s = [torch.empty(B, Hc, W, device=DEV) for _ in surf]
+        out_a = [torch.empty(B, len(levels), Hc, W, device=DEV) for _ in atmos]
+        io = lib.HipStepIO()
+        io.B, io.T, io.rollout_step = B, T, rollout_step
+        ptr = lambda ts: _carr(ctypes.c_void_p, [t.data_ptr() for t in ts])  # noqa: E731
+        keep = [ptr(surf), ptr(static), ptr(atmos), ptr(out_s), ptr(out_a)]
+        io.surf, io.stat, io.atmos, io.out_surf, io.out_atmos = keep
+        io.surf_strides[:] = surf[0].stride()
+        io.static_strides[:] = static[0].stride()
+        io.atmos_strides[:] = atmos[0].stride()
+        self.check(self.L.aurora_hip_step(self.h, ctypes.byref(io), None))   # stream 0
+        torch.cuda.synchronize()
+        return out_s, out_a
+
+    def close(self):
+        self.L.aurora_hip_destroy(self.h)
+
+
+@pytest.mark.parametrize("name", ["base_pad", "small_b2", "lora_all", "stabilised_12h", "patch10"])
+def test_c_abi_rollout_matches_reference_golden(name):
+    case, meta = helpers.case_model_meta(name)
+    cfg = meta.config
+    sd = {k: v.numpy() for k, v in helpers.case_state_dict(meta, torch.float32).items()}
+    surf, static, atmos, lat, lon, times = helpers.case_inputs(case, cfg)
+    gold = helpers.load_golden(name)
+    levels = tuple(case["levels"])
+    h = Handle(cfg, autocast=False, state_dict=sd)
+    h.precompute(lat.tolist(), lon.tolist(), levels)
+    f = lambda d, names: [d[n].float().to(DEV).contiguous() for n in names]  # noqa: E731
+    s_in, t_in, a_in = f(surf, cfg.surf_vars), f(static, cfg.static_vars), f(atmos, cfg.atmos_vars)
+    P = cfg.patch_size
+    Hc = case["H"] - case["H"] % P
+    worst = 0.0
+    for step in range(case["steps"]):
+        out_s, out_a = h.step(s_in, t_in, a_in, times, step, levels)
+        for kind, names, outs in (("surf", cfg.surf_vars, out_s), ("atmos", cfg.atmos_vars, out_a)):
+            for n, o in zip(names, outs):
+                ref = torch.from_numpy(gold[f"s{step}.{kind}.{n}"])      # (B, 1, [C,] H', W)
+                got = o.cpu().reshape(ref.shape)
+                e = helpers.mean_rel_err(got, ref)
+                worst = max(worst, e)
+                assert e <= 1e-4 and helpers.rel_err(got, ref) <= 1e-3, (step, kind, n, e)
+        # the caller's side of rollout(): drop the oldest state, append the prediction (rollout.py:39-49)
+        s_in = [torch.cat([x[:, 1:, :Hc], o[:, None]], dim=1).contiguous() for x, o in zip(s_in, out_s)]
+        a_in = [torch.cat([x[:, 1:, :, :Hc], o[:, None]], dim=1).contiguous() for x, o in zip(a_in, out_a)]
+        t_in = [x[:Hc].contiguous() for x in t_in]
+        times = tuple(t + cfg.timestep for t in times)
+        if step == 0 and case["H"] != Hc:
+            h.precompute(lat[:Hc].tolist(), lon.tolist(), levels)     # the cropped grid from now on
+    print(name, "C-ABI roll-out worst mean-rel", worst)
+    h.close()
+
+
+def test_c_abi_step_equals_python_sequenced_step(monkeypatch):
+    """The handle and the Python-sequenced engine launch the same kernels in the same order: bit-identical results
+    (fp32 and bf16), when both take their position / scale tables from the same source."""
+    from aurora_amd import Batch, Metadata
+
+    case = CASES["base_pad"]
+    for autocast in (False, True):
+        outs = []
+        for native in ("1", "0"):
+            monkeypatch.setenv("AURORA_NATIVE_STEP", native)
+            model = aurora_amd.Aurora(**case["kwargs"], autocast=autocast)
+            model.load_state_dict(helpers.case_state_dict(model, torch.float32))
+            model = model.to(DEV).eval()
+            surf, static, atmos, lat, lon, times = helpers.case_inputs(case, model.config)
+            g = lambda d: {k: v.float() for k, v in d.items()}  # noqa: E731
+            batch = Batch(g(surf), g(static), g(atmos), Metadata(lat.float(), lon.float(), times, tuple(case["levels"])))
+            with torch.inference_mode():
+                pred = model.forward(batch)
+            assert (model.engine().native is not None) == (native == "1")
+            outs.append(pred)
+        for k in outs[0].surf_vars:
+            assert torch.equal(outs[0].surf_vars[k], outs[1].surf_vars[k]), (autocast, k)
+        for k in outs[0].atmos_vars:
+            assert torch.equal(outs[0].atmos_vars[k], outs[1].atmos_vars[k]), (autocast, k)
+
+
+def test_c_abi_argument_errors():
+    L = lib.load()
+    c = lib.HipConfig()
+    h = ctypes.c_void_p()
+    assert L.aurora_hip_create(ctypes.byref(c), ctypes.byref(h)) == -1      # zero stages
+    assert b"stages" in L.aurora_hip_last_error()
+    assert L.aurora_hip_step(None, None, None) == -1

@@ -173,3 +173,45 @@ def test_graph_captured_rollout_equals_eager(name, autocast):
             assert torch.equal(g.atmos_vars[k], e.atmos_vars[k]), k
     # predictions handed out earlier are not overwritten by later replays
     assert not torch.equal(graphed[0].surf_vars["2t"], graphed[1].surf_vars["2t"])
+
+
+def test_rollout_history_windows_equal_the_reference_cat_loop():
+    """`rollout` slides a window over history chunks and lets the model write each prediction into the next slot; the
+    reference's loop (rollout.py:39-49: forward, then `cat([old[:, 1:], pred])`) must give the same states, across a
+    chunk boundary (12 steps > 8 slots) and with earlier predictions still intact afterwards."""
+    case, model, batch = build("small_b2")       # B = 2: predictions are copied into the slots
+    case1, model1, batch1 = build("base_pad")    # B = 1: predictions are written in place
+    for mdl, bt in ((model, batch), (model1, batch1)):
+        steps = 12
+        with torch.inference_mode():
+            got = list(rollout(mdl, bt, steps=steps))
+            b = bt.type(torch.float32).crop(mdl.patch_size).to("cuda")
+            want = []
+            for _ in range(steps):
+                p = mdl.forward(b)
+                want.append(p)
+                b = dataclasses.replace(
+                    p, surf_vars={k: torch.cat([b.surf_vars[k][:, 1:], v], dim=1) for k, v in p.surf_vars.items()},
+                    atmos_vars={k: torch.cat([b.atmos_vars[k][:, 1:], v], dim=1) for k, v in p.atmos_vars.items()})
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert g.metadata.time == w.metadata.time and g.metadata.rollout_step == w.metadata.rollout_step
+            for k in w.surf_vars:
+                assert torch.equal(g.surf_vars[k], w.surf_vars[k]), k
+            for k in w.atmos_vars:
+                assert torch.equal(g.atmos_vars[k], w.atmos_vars[k]), k
+
+
+def test_rollout_to_host_overlaps_and_equals_device_rollout():
+    case, model, batch = build("base_pad")
+    with torch.inference_mode():
+        dev = list(rollout(model, batch, steps=4))
+        host = list(rollout(model, batch, steps=4, to_host=True))
+    assert len(host) == 4
+    for d, h in zip(dev, host):
+        assert h.metadata.rollout_step == d.metadata.rollout_step and h.metadata.time == d.metadata.time
+        for k, v in d.surf_vars.items():
+            assert not h.surf_vars[k].is_cuda and h.surf_vars[k].is_pinned()
+            assert torch.equal(h.surf_vars[k], v.cpu()), k
+        for k, v in d.atmos_vars.items():
+            assert torch.equal(h.atmos_vars[k], v.cpu()), k

@@ -72,16 +72,12 @@ def test_linear_fp32_by_bf16_splitting_is_fp32_grade(M, N, K):
     ref = a.double() @ w.double().T
     scale = a.double().abs() @ w.double().abs().T
     err = {}
-    prev = L.set_f32_gemm(-1)
-    try:
-        for mode in (0, 1, 2):
-            L.set_f32_gemm(mode)
-            out = torch.empty((M, N), device=DEV)
+    for mode in (0, 1, 2):
+        out = torch.empty((M, N), device=DEV)
+        with L.f32_gemm(mode):
             L.linear(a.to(DEV), w.to(DEV), None, out)
-            torch.cuda.synchronize()
-            err[mode] = ((out.double().cpu() - ref).abs() / scale).max().item()
-    finally:
-        L.set_f32_gemm(prev)
+        torch.cuda.synchronize()
+        err[mode] = ((out.double().cpu() - ref).abs() / scale).max().item()
     print(f"fp32 linear {M}x{N}x{K}: native MFMA err {err[0]:.2e}, 3xbf16 split err {err[1]:.2e}, "
           f"2xfp16 split err {err[2]:.2e}")
     assert err[0] < 2e-6, err
@@ -109,13 +105,14 @@ def test_linear_fp32_range_guard_picks_the_split_on_the_device(amax):
     assert abs(measured.item() - a.abs().max().item()) == 0.0
     assert torch.isfinite(out).all()
     assert relerr(out, ref) < 2e-6
-    assert L.set_f32_gemm(-1) == 1   # the mode is restored
+    assert L._f32_state() == (-1, None, 0.0)   # the per-thread mode is restored; the library has no state at all
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (130, 64, 64), (1000, 1536, 512), (129, 80, 2048),
                                    # the 256 x 256 ring kernel: 2, 4, 6 and 32 stages, ragged M
                                    (1030, 256, 64), (1500, 512, 128), (1100, 768, 192), (4099, 1536, 1024),
-                                   # K <= 512: the persistent streamed-weights kernel; 516 tiles on 256 CUs, ragged M
+                                   # more tiles than CUs, ragged last m-tile: the persistent ring kernel (N >= 1024) and the
+                                   # plain one (N = 512)
                                    (66001, 512, 256), (33000, 1024, 512)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_linear_bf16(M, N, K, act):

@@ -32,7 +32,7 @@ def wrapped(a, w, bias, out, **kw):
         torch.cuda.synchronize()
         n = kw.get("n") or w.shape[0]
         bad = not torch.isfinite(out[:, :n]).all().item()
-        mode = lib.set_f32_gemm(-1)
+        mode = lib._f32_state()[0]
         print(f"linear M={a.shape[0]} N={n} K={a.shape[1]} mode={mode} act={kw.get('act', 0)} max|a|={a.abs().max().item():.3g} "
               f"max|w|={w.abs().max().item():.3g} max|out|={out[:, :n].abs().max().item():.3g} {'NON-FINITE' if bad else ''}")
     return r
