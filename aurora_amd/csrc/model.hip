@@ -237,7 +237,8 @@ struct aurora_hip_model {
   std::vector<std::string> surf_vars, static_vars, atmos_vars;
 
   // weights
-  std::map<std::string, Tensor> w;
+  std::map<std::string, Tensor> w;                // fp32 masters (aurora_hip_pack_weights / a packed file)
+  std::map<std::string, Tensor> w16;              // bf16-only entries of a packed file (shape kept, data bf16)
   bool finalized = false;
   std::vector<Block> blocks;
   DevBuf mod, lead_emb, enc_q0;
@@ -378,11 +379,20 @@ int lora_key(const Model& m, int step) {   // lora.py:105-129; -1 = no LoRA
   return step;                                          // all
 }
 
-// The weight `name` in the backbone compute dtype: the fp32 master itself, or a bf16 copy made once.
-const void* compute_copy(Model& m, const float* src, int64_t n, void* stream) {
-  if (!m.autocast) return src;
-  DevBuf b((size_t)n * 2);
-  ok(aurora_hip_convert(src, b.p, n, AURORA_F32, stream));
+// A backbone weight in the compute dtype: the fp32 master itself (autocast off), the bf16 entry of a packed file, or a
+// bf16 copy of the master made once.  `out_shape0` receives the leading dimension (hidden sizes are read off weights).
+const void* compute_weight(Model& m, const std::string& name, void* stream, int64_t* out_shape0 = nullptr) {
+  auto h = m.w16.find(name);
+  if (h != m.w16.end()) {
+    REQUIRE(m.autocast, "'%s' is stored in bf16 only: this packed file serves autocast (bf16 backbone) models", name.c_str());
+    if (out_shape0) *out_shape0 = h->second.shape[0];
+    return h->second.buf.p;
+  }
+  const Tensor& t = m.T_(name);
+  if (out_shape0) *out_shape0 = t.shape[0];
+  if (!m.autocast) return t.f();
+  DevBuf b((size_t)t.numel * 2);
+  ok(aurora_hip_convert(t.f(), b.p, t.numel, AURORA_F32, stream));
   m.keep.push_back(std::move(b));
   return m.keep.back().p;
 }
@@ -538,6 +548,10 @@ const AttnSet& attn_weights(Model& m, int key, void* stream) {
   for (const Block& blk : m.blocks) {
     for (int which = 0; which < 2; ++which) {
       const std::string name = blk.prefix + (which == 0 ? ".attn.qkv" : ".attn.proj");
+      if (key < 0 && m.w16.count(name + ".weight")) {   // packed bf16 file of a model without LoRA
+        (which == 0 ? set.qkv : set.proj).push_back(compute_weight(m, name + ".weight", stream));
+        continue;
+      }
       const Tensor& wt = m.T_(name + ".weight");
       const int64_t out_f = wt.shape[0], in_f = wt.shape[1];
       const float* src = wt.f();
@@ -933,6 +947,99 @@ extern "C" int aurora_hip_pack_weights(aurora_hip_model* m, const char* name, co
   })
 }
 
+// ---- packed weight files -----------------------------------------------------------------------------
+// One self-describing binary that any host can read without pickle / torch:
+//   "AURORAHIP1\0" | u32 n_entries | per entry: u32 name_len, name, u32 dtype (0 f32, 1 bf16), u32 ndim, i64 shape[ndim],
+//   u64 n_bytes, raw little-endian data
+// Saved by a FINALIZED handle: the large backbone matrices (MLP, merge / split, and the attention projections of models
+// without LoRA) are written in bf16 when the handle runs the bf16 backbone -- exactly the bits the GEMMs consume --
+// everything else as the fp32 master.  1.3 B parameters: 2.6 GB instead of 5 GB.
+namespace {
+const char PACK_MAGIC[] = "AURORAHIP1";
+
+bool backbone_matrix(const Model& m, const std::string& name) {
+  if (name.rfind("backbone.", 0) != 0 || name.size() < 7 || name.compare(name.size() - 7, 7, ".weight") != 0) return false;
+  for (const char* tag : {".mlp.fc1.", ".mlp.fc2.", ".downsample.reduction.", ".upsample.lin1.", ".upsample.lin2."})
+    if (name.find(tag) != std::string::npos) return true;
+  if (!m.use_lora && (name.find(".attn.qkv.") != std::string::npos || name.find(".attn.proj.") != std::string::npos)) return true;
+  return false;
+}
+}  // namespace
+
+extern "C" int aurora_hip_save_packed(aurora_hip_model* mp, const char* path, void* stream) {
+  GUARDED({
+    REQUIRE(mp && path, "save_packed: null argument");
+    Model& m = *mp;
+    FILE* f = fopen(path, "wb");
+    REQUIRE(f != nullptr, "save_packed: cannot open '%s' for writing", path);
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+    auto put = [&](const void* p, size_t n) { REQUIRE(fwrite(p, 1, n, f) == n, "save_packed: short write"); };
+    put(PACK_MAGIC, sizeof(PACK_MAGIC));
+    const uint32_t n_entries = (uint32_t)(m.w.size() + m.w16.size());
+    put(&n_entries, 4);
+    std::vector<char> host;
+    auto entry = [&](const std::string& name, const Tensor& t, uint32_t dtype, const void* dev, size_t bytes) {
+      const uint32_t len = (uint32_t)name.size(), nd = (uint32_t)t.shape.size();
+      put(&len, 4); put(name.data(), len); put(&dtype, 4); put(&nd, 4);
+      for (int64_t d : t.shape) put(&d, 8);
+      const uint64_t nb = bytes;
+      put(&nb, 8);
+      host.resize(bytes);
+      hip_ok(hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost), "save_packed download");
+      put(host.data(), bytes);
+    };
+    for (const auto& kv : m.w) {
+      if (m.autocast && backbone_matrix(m, kv.first)) {
+        DevBuf h((size_t)kv.second.numel * 2);
+        ok(aurora_hip_convert(kv.second.f(), h.p, kv.second.numel, AURORA_F32, stream));
+        hip_ok(hipStreamSynchronize(as_stream(stream)), "save_packed");
+        entry(kv.first, kv.second, AURORA_BF16, h.p, (size_t)kv.second.numel * 2);
+      } else {
+        entry(kv.first, kv.second, AURORA_F32, kv.second.f(), (size_t)kv.second.numel * 4);
+      }
+    }
+    for (const auto& kv : m.w16) entry(kv.first, kv.second, AURORA_BF16, kv.second.buf.p, (size_t)kv.second.numel * 2);
+  })
+}
+
+extern "C" int aurora_hip_load_packed(aurora_hip_model* mp, const char* path) {
+  GUARDED({
+    REQUIRE(mp && path, "load_packed: null argument");
+    Model& m = *mp;
+    FILE* f = fopen(path, "rb");
+    REQUIRE(f != nullptr, "load_packed: cannot open '%s'", path);
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+    auto get = [&](void* p, size_t n) { REQUIRE(fread(p, 1, n, f) == n, "load_packed: truncated file"); };
+    char magic[sizeof(PACK_MAGIC)];
+    get(magic, sizeof(magic));
+    REQUIRE(memcmp(magic, PACK_MAGIC, sizeof(PACK_MAGIC)) == 0, "load_packed: '%s' is not a packed aurora_hip weight file", path);
+    uint32_t n_entries = 0;
+    get(&n_entries, 4);
+    std::vector<char> host;
+    for (uint32_t e = 0; e < n_entries; ++e) {
+      uint32_t len = 0, dtype = 0, nd = 0;
+      get(&len, 4);
+      REQUIRE(len < 4096, "load_packed: corrupt entry");
+      std::string name(len, '\0');
+      get(&name[0], len);
+      get(&dtype, 4); get(&nd, 4);
+      REQUIRE(nd <= 8 && dtype <= 1, "load_packed: corrupt entry '%s'", name.c_str());
+      Tensor t;
+      t.numel = 1;
+      for (uint32_t i = 0; i < nd; ++i) { int64_t d; get(&d, 8); t.shape.push_back(d); t.numel *= d; }
+      uint64_t nb = 0;
+      get(&nb, 8);
+      REQUIRE(nb == (uint64_t)t.numel * (dtype == AURORA_F32 ? 4 : 2), "load_packed: size mismatch in '%s'", name.c_str());
+      host.resize(nb);
+      get(host.data(), nb);
+      t.buf = DevBuf(nb);
+      upload(t.buf.p, host.data(), nb);
+      (dtype == AURORA_F32 ? m.w : m.w16)[name] = std::move(t);
+    }
+    m.finalized = false;
+  })
+}
+
 extern "C" int aurora_hip_finalize(aurora_hip_model* mp, void* stream) {
   GUARDED({
     REQUIRE(mp != nullptr, "finalize: null model");
@@ -967,22 +1074,18 @@ extern "C" int aurora_hip_finalize(aurora_hip_model* mp, void* stream) {
     for (Block& b : m.blocks) {   // chunk(2): shift first, then scale (film.py:48); scale_bias is 0 in every config
       b.shift1 = m.mod.f() + off; b.gain1 = m.mod.f() + off + b.dim; off += 2 * b.dim;
       b.shift2 = m.mod.f() + off; b.gain2 = m.mod.f() + off + b.dim; off += 2 * b.dim;
-      const Tensor& f1 = m.T_(b.prefix + ".mlp.fc1.weight");
-      b.hidden = (int)f1.shape[0];
-      b.fc1_w = compute_copy(m, f1.f(), f1.numel, stream);
-      const Tensor& f2 = m.T_(b.prefix + ".mlp.fc2.weight");
-      b.fc2_w = compute_copy(m, f2.f(), f2.numel, stream);
+      int64_t hidden = 0;
+      b.fc1_w = compute_weight(m, b.prefix + ".mlp.fc1.weight", stream, &hidden);
+      b.hidden = (int)hidden;
+      b.fc2_w = compute_weight(m, b.prefix + ".mlp.fc2.weight", stream);
       b.fc1_b = m.W(b.prefix + ".mlp.fc1.bias"); b.fc2_b = m.W(b.prefix + ".mlp.fc2.bias");
       b.qkv_b = m.W(b.prefix + ".attn.qkv.bias"); b.proj_b = m.W(b.prefix + ".attn.proj.bias");
     }
     for (int i = 0; i + 1 < m.n_stages; ++i) {
       const std::string p = "backbone.encoder_layers." + std::to_string(i) + ".downsample";
-      const Tensor& r = m.T_(p + ".reduction.weight");
-      m.merges.push_back({compute_copy(m, r.f(), r.numel, stream), m.W(p + ".norm.weight"), m.W(p + ".norm.bias")});
+      m.merges.push_back({compute_weight(m, p + ".reduction.weight", stream), m.W(p + ".norm.weight"), m.W(p + ".norm.bias")});
       const std::string q = "backbone.decoder_layers." + std::to_string(i) + ".upsample";
-      const Tensor& l1 = m.T_(q + ".lin1.weight");
-      const Tensor& l2 = m.T_(q + ".lin2.weight");
-      m.splits.push_back({compute_copy(m, l1.f(), l1.numel, stream), compute_copy(m, l2.f(), l2.numel, stream),
+      m.splits.push_back({compute_weight(m, q + ".lin1.weight", stream), compute_weight(m, q + ".lin2.weight", stream),
                           m.W(q + ".norm.weight"), m.W(q + ".norm.bias")});
     }
     attn_weights(m, -1, stream);

@@ -472,6 +472,8 @@ _SIGNATURES.update({
     "aurora_hip_destroy": (None, [c_void_p]),
     "aurora_hip_pack_weights": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.POINTER(c_int64), c_int, c_int, c_int]),
     "aurora_hip_finalize": (c_int, [c_void_p, c_void_p]),
+    "aurora_hip_save_packed": (c_int, [c_void_p, ctypes.c_char_p, c_void_p]),
+    "aurora_hip_load_packed": (c_int, [c_void_p, ctypes.c_char_p]),
     "aurora_hip_precompute": (c_int, [c_void_p, ctypes.POINTER(HipGrid), c_void_p]),
     "aurora_hip_set_time": (c_int, [c_void_p, _PD, c_int, c_void_p]),
     "aurora_hip_step": (c_int, [c_void_p, ctypes.POINTER(HipStepIO), c_void_p]),

@@ -90,6 +90,11 @@ class NativeModel:
             except Exception:   # interpreter shutdown
                 pass
 
+    def save_packed(self, path: str) -> None:
+        """Write the handle's weights as a packed file (include/aurora_hip.h: aurora_hip_save_packed): what a host
+        without Python loads with `aurora_hip_load_packed` instead of unpickling a checkpoint."""
+        lib._check(lib.load().aurora_hip_save_packed(self._h, str(path).encode(), lib._stream()))
+
     # -- per grid / level set ---------------------------------------------------------------------------------
     def _precompute(self, lat: torch.Tensor, lon: torch.Tensor, levels: tuple, H: int, W: int) -> None:
         # storage identity first (no device->host copy per step), then content

@@ -46,6 +46,8 @@ LEVELS = (50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000)
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (6.29 TB/s measured achievable)
 FLOP_PER_STEP = 96.8e12
+# A (M x K) + W (N x K) read once, C (M x N) written once, bf16, averaged over the 198 bf16 linears of a step
+ALGO_BYTES_PER_GEMM_LAUNCH = 579.0e6
 
 
 def synthetic_batch(cfg, H, W, seed, device, levels=LEVELS):
@@ -238,10 +240,12 @@ def main() -> None:
         a = prof.get("window_attention_bf16", {"launches": 0, "ms": 0.0, "work": 0.0})
         gemm_tf = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else 0.0
         attn_gbs = a["work"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] else 0.0
+        # HBM-side bytes per launch of the dominant kernel come from hardware counters, which only rocprofv3 can collect:
+        # the tracked PMC summary of THIS command (tools/profile_round.sh -> tools/pmc_rollup.py), not a live value.
         traffic = None
-        pmc = ROOT / "profiles" / "pmc_summary.json"
-        if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get("linear_bf16_hbm_bytes_per_launch")
+        pmc = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))
+        if pmc:
+            traffic = json.loads(pmc[-1].read_text()).get("linear_bf16_hbm_bytes_per_launch")
         out = {
             "metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13",
             "value": value, "unit": "forecast-steps/s", "n_gpus": world, "steps": args.steps,
@@ -259,6 +263,9 @@ def main() -> None:
                 "kernel": "linear_kernel<bf16> (MFMA GEMM, all backbone linears)", "bound": "mfma",
                 "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": traffic,
+                "traffic_source": f"profiles/{pmc[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command; "
+                                  "2 x FETCH_SIZE per profiles/r02_fetch_calibration.txt)" if pmc else None,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_GEMM_LAUNCH,
                 "launches_per_step": g["launches"] / max(args.steps, 1),
                 "ms_per_step": g["ms"] / max(args.steps, 1),
                 "attention": {"kernel": "window_attention_bf16", "bound": "hbm", "achieved": attn_gbs,

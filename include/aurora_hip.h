@@ -310,6 +310,14 @@ void aurora_hip_destroy(aurora_hip_model* model);
 int aurora_hip_pack_weights(aurora_hip_model* model, const char* name, const void* data, const int64_t* shape, int ndim,
                             int dtype, int on_device);
 int aurora_hip_finalize(aurora_hip_model* model, void* stream);
+/* Packed weight files: a self-describing binary ("AURORAHIP1", entries of name / dtype / shape / raw data) that replaces
+ * the pickled `.ckpt` + adapters (aurora.py:432-456, compat.py) for hosts without Python.  _save_packed writes what a
+ * finalized handle holds -- the large backbone matrices in bf16 when the handle runs the bf16 backbone (the bits the
+ * GEMMs consume: 2.6 GB instead of 5 GB for the 1.3 B model), the rest as fp32 -- and _load_packed fills a freshly created
+ * handle from such a file instead of aurora_hip_pack_weights calls (then _finalize as usual).  bf16-only files serve
+ * autocast handles; LoRA models keep fp32 attention projections (the merge W + BA is done in fp32). */
+int aurora_hip_save_packed(aurora_hip_model* model, const char* path, void* stream);
+int aurora_hip_load_packed(aurora_hip_model* model, const char* path);
 int aurora_hip_precompute(aurora_hip_model* model, const aurora_hip_grid* grid, void* stream);
 /* Absolute times of the batch elements in hours since the Unix epoch (encoder.py:359-363), host pointer. */
 int aurora_hip_set_time(aurora_hip_model* model, const double* time_hours, int B, void* stream);

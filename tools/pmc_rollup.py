@@ -1,0 +1,41 @@
+"""Roll the per-kernel PMC summary (tools/pmc_summary.py, written by tools/profile_round.sh) up into the figures
+bench.py and DESIGN.md quote:
+
+    python tools/pmc_rollup.py gpurun_out/r02_pmc_summary.json profiles/r02_pmc_summary.json
+
+  linear_bf16_*  launch-weighted means over the two bf16 GEMM kernels (ring and persistent)
+  traffic        = 2 x FETCH_SIZE + WRITE_SIZE: FETCH_SIZE is doubled for the GEMM's LDS-DMA pattern as measured by
+                   tools/probes/fetch_calib.hip (profiles/r02_fetch_calibration.txt: 0.500 of the bytes for the
+                   16-rows-x-64-B pattern, the 8-rows-x-128-B pattern and a contiguous stream alike); WRITE_SIZE is
+                   taken at face value -- it reproduces the algorithmic output bytes of the persistent kernel's 134
+                   launches per step to 0.1 % (391 MB).
+"""
+import json
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+d = json.load(open(src))
+gemm = {k: v for k, v in d.items() if k.startswith("linear_kernel_256p") or k.startswith("linear_kernel_256<unsigned short")}
+n = {k: v["launches"]["fetch"] for k, v in gemm.items()}
+tot = sum(n.values())
+w = lambda key: sum(v[key] * n[k] for k, v in gemm.items()) / tot  # noqa: E731
+out = {
+    "_about": "rocprofv3 --pmc passes (FETCH_SIZE+GRBM_GUI_ACTIVE, WRITE_SIZE, SQ counters: three separate runs, "
+              "tools/profile_round.sh) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`, aggregated per kernel by "
+              "tools/pmc_summary.py and rolled up by tools/pmc_rollup.py; values are means per launch.",
+    "_calibration": "FETCH_SIZE reports 0.500 of the bytes actually read for all three access patterns probed "
+                    "(profiles/r02_fetch_calibration.txt), so reads = 2 x FETCH_SIZE x 1024 B for every kernel here, the GEMM "
+                    "included (round 1 took x1 for the GEMM: wrong).  FETCH_SIZE counts L2 misses on the fabric side: "
+                    "Infinity-Cache hits are included, so this is L2-miss traffic, an upper bound of HBM traffic.",
+    "linear_bf16_launches_profiled": tot,
+    "linear_bf16_read_bytes_per_launch": 2.0 * w("FETCH_SIZE_per_launch") * 1024,
+    "linear_bf16_write_bytes_per_launch": w("WRITE_SIZE_per_launch") * 1024,
+    # MFMA-busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs: busy / (GRBM / 8 * 1024)
+    "linear_bf16_mfma_busy_fraction": w("SQ_VALU_MFMA_BUSY_CYCLES_per_launch") / (w("GRBM_GUI_ACTIVE_per_launch") * 128),
+}
+out["linear_bf16_hbm_bytes_per_launch"] = out["linear_bf16_read_bytes_per_launch"] + out["linear_bf16_write_bytes_per_launch"]
+att = next(v for k, v in d.items() if k.startswith("window_attention_bf16"))
+out["window_attention_bf16_hbm_bytes_per_launch"] = 2.0 * att["FETCH_SIZE_per_launch"] * 1024 + att["WRITE_SIZE_per_launch"] * 1024
+out["per_kernel"] = d
+json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+print(json.dumps({k: v for k, v in out.items() if k != "per_kernel"}, indent=1))
