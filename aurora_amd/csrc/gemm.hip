@@ -681,6 +681,7 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
 // Bias values are fetched before the last K-stage's wait and pinned there (hipcc would otherwise wait vmcnt(0) at their
 // first use, draining the prologue it has just issued).
 // =================================================================================================
+constexpr int MID_LDS = 3 * (BM2 + 128) * ROW2;   // 256 x 128 tiles: three stages of 24 KiB, two workgroups per CU
 constexpr int PERSIST_LDS = NSTAGE2 * STAGE2 + 8 * 2048 + 2 * 2048;   // ring | result transpose (2 KiB per wave) | bias x 2
 
 template <int PRIO>
@@ -1186,17 +1187,35 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
   // would round differently from the same rows of the un-sharded one.)
   const bool split = dtype == AURORA_F32 && mode >= 1;
   bool big = (M >= 1024 || split) && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
+  bool mid = false;   // bf16 only: 256 x 128 tiles of the ring kernel, two 4-wave workgroups per CU
   if (big && !split) {
     // Few tiles (a latitude band of a sharded model, the coarse stages): 256 x 256 tiles leave CUs idle or end in a
-    // thin last round, where 128 x 128 tiles (two workgroups per CU, ~0.8 of the big kernel's rate when both are
-    // full) fill the chip.  Compare the fill of the rounds each tiling needs (measured, tools/gemm_bench.py r8.*).
+    // thin last round.  Smaller tiles fill the chip: 256 x 128 tiles of the same ring kernel (two 4-wave workgroups per
+    // CU, each with the full 128 x 64 wave tile) or 128 x 128 tiles.  The choice is a cost model fitted to measurements
+    // (profiles/r02_ab_gemm_tiles.log): a round of tiles costs a + b K microseconds -- 256^2: 10.1 + 0.0266 K (256 per
+    // round), 256 x 128: 7.7 + 0.0317 K (512 per round), 128^2: 7.6 + 0.0153 K (512 per round) -- and a last round that
+    // leaves every CU with at most one of its two workgroups runs in ~0.65 of that.  (Results do not depend on the
+    // tiling: every kernel accumulates K in the same 32-wide steps.)
     const int64_t cus = device_cus();
     const int64_t nb_big = ((M + BM2 - 1) / BM2) * (N / BN2), nb_small = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    const double fill_big = (double)nb_big / (double)(((nb_big + cus - 1) / cus) * cus);
-    const double fill_small = (double)nb_small / (double)(((nb_small + 2 * cus - 1) / (2 * cus)) * 2 * cus);
-    if (0.8 * fill_small > fill_big) big = false;
+    const int64_t nb_mid = ((M + BM2 - 1) / BM2) * (N / 128);
+    static const int force = [] { const char* e = getenv("AURORA_GEMM_TILE"); return !e ? 0 : e[0] == 'b' ? 1 : e[0] == 'm' ? 2 : 3; }();
+    if (dtype == AURORA_BF16) {
+      auto cost = [&](int64_t nb, int64_t slots, double a, double b) {
+        const int64_t full = nb / slots, rem = nb % slots;
+        const double part = rem == 0 ? 0.0 : (slots > cus && rem <= cus) ? 0.65 : 1.0;
+        return ((double)full + part) * (a + b * (double)K);
+      };
+      const double t_big = cost(nb_big, cus, 10.1, 0.0266), t_mid = cost(nb_mid, 2 * cus, 7.7, 0.0317),
+                   t_small = cost(nb_small, 2 * cus, 7.6, 0.0153);
+      if (force == 2 || (force == 0 && t_mid < 0.97 * t_big && t_mid <= t_small)) mid = true;
+      else if (force == 3 || (force == 0 && t_small < 0.97 * t_big)) big = false;
+    } else {
+      auto fill = [&](int64_t nb, int64_t slots) { return (double)nb / (double)(((nb + slots - 1) / slots) * slots); };
+      if (force == 3 || (force == 0 && 0.8 * fill(nb_small, 2 * cus) > fill(nb_big, cus))) big = false;
+    }
   }
-  const int bm = big ? BM2 : BM, bn = big ? BN2 : BN, rowb = big ? ROW2 : ROW_BYTES;
+  const int bm = big ? BM2 : BM, bn = mid ? 128 : big ? BN2 : BN, rowb = big ? ROW2 : ROW_BYTES;
   LinearArgs p;
   p.A = (const char*)A; p.lda_b = lda * es;
   p.W = (const char*)W; p.ldw_b = ldw * es;
@@ -1224,13 +1243,16 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<float, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 2, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256p<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256p<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     attr_done = true;
   }
-  if (big) {
+  if (mid) {
+    hipLaunchKernelGGL((linear_kernel_256<bf16_t, 2, 3, 0>), grid, dim3(256), MID_LDS, as_stream(stream), p);
+  } else if (big) {
     if (split && mode == 2 && g_guard != nullptr) {   // both variants; the device word picks one
       hipLaunchKernelGGL(linear_kernel_256_f32x3<2>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
       hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);

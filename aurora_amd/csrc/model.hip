@@ -219,6 +219,7 @@ struct Resampler {
     const float *ln_k_w = nullptr, *ln_k_b = nullptr, *ln_q_w = nullptr, *ln_q_b = nullptr;
     int inner, head_dim, hidden, dim;
     float v_l1;
+    int f16_mode;   // fp32 GEMM mode of this layer's bounded linears: 2 (two fp16 terms) when weights / LN bounds allow
   };
   std::vector<Layer> layers;
 };
@@ -418,6 +419,14 @@ void build_blocks(Model& m) {
     }
 }
 
+constexpr float F16_SAFE = 16384.0f;   // activations below this may take the two-term fp16 operand split
+// fp32 GEMM mode of the linears whose input is bounded (by construction or by the device-side guard): the two-term fp16
+// split, unless the user pinned a mode through AURORA_F32_GEMM
+int bounded_mode() {
+  static const int mode = getenv("AURORA_F32_GEMM") ? -1 : 2;
+  return mode;
+}
+
 Resampler pack_resampler(Model& m, const std::string& prefix, int depth, int heads) {
   Resampler r;
   for (int i = 0; i < depth; ++i) {
@@ -449,18 +458,27 @@ Resampler pack_resampler(Model& m, const std::string& prefix, int depth, int hea
       best = std::max(best, s);
     }
     l.v_l1 = best;
+    // The two-term fp16 split scales weights by 2^6 and assumes |activation| < 65504: only if every weight of the layer
+    // stays below 1000 and what a LayerNorm output can reach (sqrt(D) max|gain| + max|bias|) stays inside the range.
+    auto absmax_of = [&](const std::string& name) {
+      const Tensor& t = m.T_(name);
+      std::vector<float> h((size_t)t.numel);
+      hip_ok(hipMemcpy(h.data(), t.f(), h.size() * 4, hipMemcpyDeviceToHost), "download");
+      float mx = 0.f;
+      for (float v : h) mx = std::max(mx, fabsf(v));
+      return mx;
+    };
+    float w_max = 0.f;
+    for (const char* nm : {".0.to_kv.weight", ".0.to_out.weight", ".1.net.0.weight", ".1.net.2.weight"})
+      w_max = std::max(w_max, absmax_of(p + nm));
+    const float ln_bound = absmax_of(p + ".2.weight") * sqrtf((float)l.dim) + absmax_of(p + ".2.bias");
+    l.f16_mode = (w_max < 1000.f && ln_bound < F16_SAFE) ? bounded_mode() : -1;
     r.layers.push_back(l);
   }
   return r;
 }
 
-constexpr float F16_SAFE = 16384.0f;   // activations below this may take the two-term fp16 operand split
-// fp32 GEMM mode of the linears whose input is bounded (by construction or by the device-side guard): the two-term fp16
-// split, unless the user pinned a mode through AURORA_F32_GEMM
-int bounded_mode() {
-  static const int mode = getenv("AURORA_F32_GEMM") ? -1 : 2;
-  return mode;
-}
+
 
 // PerceiverResampler (perceiver.py:212-233) for all grid columns at once.  ctx: key j of column (b, l) at row
 // b*kv_bstride + j*kv_lstride + l.  First layer: latents (and so q) are shared by every column.  Returns (B*cols*Lq, D).
@@ -482,7 +500,7 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     const size_t after_y = m.arena.top;
     float* kv = (float*)m.arena.take((size_t)ctx_rows * 2 * inner * 4);
     L.linear(ctx, ctx_dim, ly.to_kv, ctx_dim, nullptr, kv, 2 * inner, ctx_rows, 2 * inner, ctx_dim, AURORA_F32, 0, nullptr, 0,
-             nullptr, 0, bounded_mode(), ctx_max, F16_SAFE);
+             nullptr, 0, ly.f16_mode, ctx_max, F16_SAFE);
     if (ly.ln_k_w)   // LayerNorm over the K half, in place (perceiver.py:144-147)
       L.layernorm(kv, 2 * inner, ly.ln_k_w, ly.ln_k_b, nullptr, 0, 0, kv, 2 * inner, nullptr, 0, ctx_rows, inner, 1e-5f,
                   AURORA_F32);
@@ -500,7 +518,7 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
                                         AURORA_F32, L.stream); });
     float* o = (float*)m.arena.take((size_t)n_rows * Dd * 4);
     // |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
-    L.linear(att, inner, ly.to_out, inner, nullptr, o, Dd, n_rows, Dd, inner, AURORA_F32, 0, nullptr, 0, nullptr, 0, bounded_mode(), ctx_max,
+    L.linear(att, inner, ly.to_out, inner, nullptr, o, Dd, n_rows, Dd, inner, AURORA_F32, 0, nullptr, 0, nullptr, 0, ly.f16_mode, ctx_max,
              F16_SAFE / ly.v_l1);
     float* lat1 = (float*)m.arena.take((size_t)n_rows * Dd * 4);
     if (i == 0) L.layernorm(o, Dd, ly.ln1_w, ly.ln1_b, latents0, Dd, Lq, lat1, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
@@ -508,9 +526,9 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     float* hid = (float*)m.arena.take((size_t)n_rows * ly.hidden * 4);
     // fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU: bounded whatever the inputs are
     L.linear(lat1, Dd, ly.fc1_w, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
-             nullptr, 0, bounded_mode());
+             nullptr, 0, ly.f16_mode);
     L.linear(hid, ly.hidden, ly.fc2_w, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0,
-             bounded_mode());
+             ly.f16_mode);
     L.layernorm(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, y, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
     m.arena.top = after_y;            // temporaries of this layer are dead (a previous layer's result stays below y)
     lat = y;

@@ -29,6 +29,7 @@ torch is used here for device memory (torch.empty / views), layout plumbing at p
 
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 import os
 from collections import OrderedDict
@@ -241,6 +242,12 @@ class Engine:
             d["head_dim"] = d["inner"] // heads
             # largest L1 row norm of the value projection: |v| <= v_l1 * max |context| (pack time, one sync)
             d["v_l1"] = max(float(d["to_kv"][d["inner"]:].abs().sum(dim=1).max().item()), 1e-6)
+            # The two-term fp16 split scales weights by 2^6 and assumes |activation| < 65504: it is only used if every
+            # weight of the layer stays below 1000 and the MLP's input bound sqrt(D) * max|LN gain| + max|LN bias|
+            # (what a LayerNorm output can reach) and its hidden layer stay inside the range; else three bf16 terms.
+            w_max = max(float(d[k].abs().max().item()) for k in ("to_kv", "to_out", "fc1_w", "fc2_w"))
+            ln_bound = float(d["ln1_w"].abs().max().item()) * d["ln1_w"].numel() ** 0.5 + float(d["ln1_b"].abs().max().item())
+            d["f16_ok"] = w_max < 1000.0 and ln_bound < _F16_SAFE
             layers.append(d)
         return layers
 
@@ -452,8 +459,6 @@ class Engine:
     def _native_step(self, batch: Batch, out=None) -> Optional[Batch]:
         """The step through the C-ABI handle; None if this batch needs the Python sequencing (a variable subset, or
         latitude / longitude matrices)."""
-        if self.is_stale():
-            raise RuntimeError("model parameters changed after packing: call model._engine = None first")
         if isinstance(batch, BandBatch) or not self.native.accepts(batch):
             if not hasattr(self, "enc_layers"):
                 self._pack_static()
@@ -499,8 +504,6 @@ class Engine:
         """Generator form of the step: yields `Exchange` requests (sharded mode only) and returns the
         prediction.  `step()` drives it with RCCL; tests drive several ranks in one process."""
         model, cfg = self.model, self.cfg
-        if self.is_stale():
-            raise RuntimeError("model parameters changed after packing: call model._engine = None first")
         if not self._capturing:  # (a captured step runs on a batch the hook has already seen)
             batch = model.batch_transform_hook(batch)
         P, D = cfg.patch_size, cfg.embed_dim
@@ -836,7 +839,8 @@ class Engine:
         ctx_max = lib.absmax(ctx)
         for i, ly in enumerate(layers):
             inner, hd = ly["inner"], ly["head_dim"]
-            with lib.bounded_activations(guard=(ctx_max, _F16_SAFE)):
+            bounded = lib.bounded_activations if ly["f16_ok"] else (lambda guard=None: contextlib.nullcontext())
+            with bounded(guard=(ctx_max, _F16_SAFE)):
                 kv = self._linear_new(ctx, ly["to_kv"], None, 2 * inner)
             if "ln_k.w" in ly:  # LayerNorm over the K half, in place (perceiver.py:144-147)
                 lib.layernorm(kv, ly["ln_k.w"], ly["ln_k.b"], out_f32=kv, d=inner)
@@ -852,7 +856,7 @@ class Engine:
             del kv
             D = ly["to_out"].shape[0]
             # |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
-            with lib.bounded_activations(guard=(ctx_max, _F16_SAFE / ly["v_l1"])):
+            with bounded(guard=(ctx_max, _F16_SAFE / ly["v_l1"])):
                 o = self._linear_new(att, ly["to_out"], None, D)
             del att
             lat1 = self.empty(n_rows, D)
@@ -861,7 +865,7 @@ class Engine:
             else:
                 lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], res=lat, out_f32=lat1, eps=eps)
             del o
-            with lib.bounded_activations():    # fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU
+            with bounded():    # fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU
                 hid = self._linear_new(lat1, ly["fc1_w"], ly["fc1_b"], ly["fc1_w"].shape[0], act=lib.ACT_GELU)
                 y = self._linear_new(hid, ly["fc2_w"], ly["fc2_b"], D)
             del hid

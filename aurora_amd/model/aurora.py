@@ -190,6 +190,11 @@ class Aurora(nn.Module):
                 "aurora_amd runs on a HIP device only: move the model with `.to('cuda')` "
                 f"before calling it (parameters are on '{p.device}'). There is no CPU path."
             )
+        if self._engine is not None and self._engine.is_stale():
+            # parameters were modified in place (optimizer step, `p.add_`, `load_state_dict` on a sub-module, ...):
+            # pack again.  Edits through `.data` or under `torch.inference_mode()` do not bump the version counters
+            # and go unnoticed -- set `model._engine = None` after those.
+            self._engine = None
         if self._engine is None:
             from aurora_amd.engine import Engine  # deferred: loads the HIP library
 

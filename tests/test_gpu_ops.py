@@ -113,7 +113,10 @@ def test_linear_fp32_range_guard_picks_the_split_on_the_device(amax):
                                    (1030, 256, 64), (1500, 512, 128), (1100, 768, 192), (4099, 1536, 1024),
                                    # more tiles than CUs, ragged last m-tile: the persistent ring kernel (N >= 1024) and the
                                    # plain one (N = 512)
-                                   (66001, 512, 256), (33000, 1024, 512)])
+                                   (66001, 512, 256), (33000, 1024, 512),
+                                   # per-rank shapes of an 8-way latitude-band split: the cost model picks 256 x 128 tiles
+                                   # (two workgroups per CU) for the first two, 128 x 128 tiles for the third
+                                   (34560, 512, 512), (8100, 3072, 1024), (2160, 2048, 2048)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_linear_bf16(M, N, K, act):
     L = lib()

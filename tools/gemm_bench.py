@@ -17,7 +17,9 @@ SHAPES = [  # (name, M, N, K, weight in the step)
     ("s2.qkv", 16200, 6144, 2048, 16), ("s2.proj", 16200, 2048, 2048, 16),
     ("s2.fc1", 16200, 8192, 2048, 16), ("s2.fc2", 16200, 2048, 8192, 16),
     ("sq4096", 4096, 4096, 4096, 0), ("sq8192", 8192, 8192, 8192, 0),
-    # per-rank shapes of an 8-way latitude-band split (stage 1: 8100 rows, stage 2: 2160 rows)
+    # per-rank shapes of an 8-way latitude-band split (stage 0: 34560 rows, stage 1: 8100 rows, stage 2: 2160 rows)
+    ("r8.s0.qkv", 34560, 1536, 512, 0), ("r8.s0.proj", 34560, 512, 512, 0), ("r8.s0.fc1", 34560, 2048, 512, 0),
+    ("r8.s0.fc2", 34560, 512, 2048, 0),
     ("r8.s1.qkv", 8100, 3072, 1024, 0), ("r8.s1.proj", 8100, 1024, 1024, 0), ("r8.s1.fc1", 8100, 4096, 1024, 0),
     ("r8.s1.fc2", 8100, 1024, 4096, 0), ("r8.s2.qkv", 2160, 6144, 2048, 0), ("r8.s2.proj", 2160, 2048, 2048, 0),
     ("r8.s2.fc1", 2160, 8192, 2048, 0), ("r8.s2.fc2", 2160, 2048, 8192, 0),
