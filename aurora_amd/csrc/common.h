@@ -60,6 +60,21 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// Two-term fp16 split of a pair of fp32 values (gemm.hip, "second variant"): h = fp16(a), l = fp16(a - h), packed two to a
+// register.  Shared by every kernel that produces the fp16-pair layout, so that a split is the same wherever it happens.
+// (The remainder could come from one mixed-precision FMA per value -- v_fma_mixlo/hi_f16: widen, subtract and round in
+// one instruction, 3 operations per pair instead of 5.  Measured: no gain in the in-phase kernel, -15 % in the ping-pong
+// one; the mix instructions do not issue at the packed conversions' rate.)
+__device__ __forceinline__ void split_pair_f16(float a0, float a1, uint32_t& h, uint32_t& l) {
+  const f32x2_t v = {a0, a1};
+  const f16x2_t hh = __builtin_convertvector(v, f16x2_t);             // v_cvt_pk_f16_f32 (round to nearest even)
+  const f32x2_t r = v - __builtin_convertvector(hh, f32x2_t);         // exact
+  h = __builtin_bit_cast(uint32_t, hh);
+  l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+}
 
 // Load `n` (4 or 8) consecutive elements as floats.
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {

@@ -58,6 +58,7 @@ struct LinearArgs {
   int tiles_n; int64_t n_blocks;
   int vec_store;                  // 1: every C/C2/res row piece is 16-byte aligned
   const float* guard; float guard_limit;   // f32 split kernels (guarded launch): two fp16 terms iff *guard < guard_limit
+  int out_split;                  // two-term ping-pong kernel: C is written in the fp16-pair layout (see aurora_hip_split_f16)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -681,10 +682,131 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
 // Bias values are fetched before the last K-stage's wait and pinned there (hipcc would otherwise wait vmcnt(0) at their
 // first use, draining the prologue it has just issued).
 // =================================================================================================
+// =================================================================================================
+// Ping-pong form of the 256 x 256 ring kernel (bf16): the two waves that share a SIMD never issue MFMAs at the same time.
+//
+// In linear_kernel_256 all eight waves run the same stream in phase -- 8 MFMAs, wait, barrier, DMA issue, 12 fragment
+// reads, 24 MFMAs -- and the two waves of a SIMD compete for its matrix pipe and issue slots (measured in round 1:
+// 1668 cycles per K-stage for 1024 cycles of MFMA work, one wave of each pair parked ~580 cycles per stage).  Here every
+// wave alternates a LOAD phase L(s) (12 fragment reads of stage s, DMA issue of stage s+3, counted waits) and a MATRIX
+// phase M(s) (32 back-to-back MFMAs), with a barrier after each -- and waves 4-7 (the SIMD partners of waves 0-3) run
+// ONE PHASE BEHIND, by a single extra barrier in front (balanced by one for waves 0-3 at the end).  So in every
+// wall-clock phase a SIMD's matrix pipe belongs to exactly one wave while its partner does the LDS / DMA work; the
+// instruction stream is the same for all waves, and fragments are read one phase before they are multiplied (one
+// register set instead of two).
+// Ring bookkeeping (per wave, iteration s): stage s+1 is published by the barrier that ends L(s) -- every wave has by
+// then waited for ITS pieces of it (vmcnt(8): stages s+2, s+3 are younger) -- and is read no earlier than L(s+1); the
+// DMA of stage s+3 in L(s) overwrites the buffer of stage s-1, whose last reader (a late wave's L(s-1), finished with
+// lgkmcnt(0) before its barrier) is at least one barrier in the past for early and late waves alike.
+// =================================================================================================
+template <int PRIO>
+__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // waves w and w+4 share a SIMD; wm = 1 runs one phase behind
+
+  uint32_t tile_m, tile_n;
+  tile_of_block(blockIdx.x, (uint32_t)p.n_blocks, (uint32_t)(p.n_blocks / p.tiles_n), (uint32_t)p.tiles_n, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM2;
+  const int n0 = (int)tile_n * BN2;
+
+  const char* src_x[2];
+  const char* src_w[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int id = r * THREADS2 + tid;
+    const int row = id >> 2, c = id & 3;
+    int64_t gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + row;
+    gn = gn < p.N ? gn : p.N - 1;
+    src_x[r] = p.A + gm * p.lda_b + ((c ^ swz2_x(row)) << 4);
+    src_w[r] = p.W + (int64_t)gn * p.ldw_b + ((c ^ swz2_w(row)) << 4);
+  }
+  auto stage = [&](int kt) {
+    const int64_t koff = (int64_t)kt * ROW2;
+    char* base = smem + (kt & (NSTAGE2 - 1)) * STAGE2;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[r] + koff),
+                                       (lds_ptr_t)(base + (r * THREADS2 + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
+                                       (lds_ptr_t)(base + OPER2 + (r * THREADS2 + wave * 64) * 16), 16, 0, 0);
+  };
+  const int i16 = lane & 15, g = lane >> 4;
+  int off_x[8], off_w[4];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const int row = wm * 128 + 16 * f + i16;
+    off_x[f] = row * ROW2 + ((g ^ swz2_x(row)) << 4);
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int row = wn * 64 + 16 * (i16 >> 2) + 4 * f + (i16 & 3);
+    off_w[f] = OPER2 + row * ROW2 + ((g ^ swz2_w(row)) << 4);
+  }
+  f32x4 acc[4][8];  // [fn][fm]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nt = p.k_tiles;   // >= 4 (dispatch)
+  stage(0);
+  stage(1);
+  stage(2);
+  stage(3);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // stage 0 is complete
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
+
+  for (int s = 0; s < nt; ++s) {
+    // ---- L(s): fragments of stage s, refill the ring, settle what the next barrier publishes ----
+    u32x4 fw[4], fx[8];
+    {
+      const char* buf = smem + (s & (NSTAGE2 - 1)) * STAGE2;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fw[f] = *reinterpret_cast<const u32x4*>(buf + off_w[f]);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) fx[f] = *reinterpret_cast<const u32x4*>(buf + off_x[f]);
+    }
+    if (s >= 1 && s + 3 < nt) stage(s + 3);   // into the buffer of stage s-1
+    if (s + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // own pieces of stage s+1 have landed
+    else if (s + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- M(s): the matrix pipe is this wave's alone ----
+    if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int fm = 0; fm < 8; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = Mma<bf16_t>::run(fw[fn], fx[fm], acc[fn][fm]);
+    if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // the early half waits for the late half's last phase: the ring is dead
+  asm volatile("" ::: "memory");
+  if (p.C2 == nullptr && p.res == nullptr && p.vec_store) {   // (uniform)
+    epilogue_256_bf16_coalesced<1>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+    return;
+  }
+  epilogue_256<bf16_t>(p, acc, m0, n0, wm, wn, i16, g);
+}
+
 constexpr int MID_LDS = 3 * (BM2 + 128) * ROW2;   // 256 x 128 tiles: three stages of 24 KiB, two workgroups per CU
 constexpr int PERSIST_LDS = NSTAGE2 * STAGE2 + 8 * 2048 + 2 * 2048;   // ring | result transpose (2 KiB per wave) | bias x 2
 
-template <int PRIO>
+// PP: the main loop in ping-pong form (linear_kernel_256pp above: waves 4-7 one phase behind waves 0-3, one fragment set).
+template <int PRIO, int PP>
 __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256p(const LinearArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -808,19 +930,43 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256p(const LinearAr
     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    u32x4 fwA[4], fxA[8], fwB[4], fxB[8];
-    read_frags(0, fwA, fxA);
-    for (int kt = 0; kt + 2 < nt; kt += 2) {
-      step(kt, fwA, fxA, fwB, fxB);
-      step(kt + 1, fwB, fxB, fwA, fxA);
+    if constexpr (PP == 0) {
+      u32x4 fwA[4], fxA[8], fwB[4], fxB[8];
+      read_frags(0, fwA, fxA);
+      for (int kt = 0; kt + 2 < nt; kt += 2) {
+        step(kt, fwA, fxA, fwB, fxB);
+        step(kt + 1, fwB, fxB, fwA, fxA);
+      }
+      step(nt - 2, fwA, fxA, fwB, fxB);  // fetches the last stage; its wait is vmcnt(0)
+      mma_rows(fwB, fxB, 0, 8);
+    } else {
+      if (wm == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
+      for (int s_ = 0; s_ < nt; ++s_) {
+        u32x4 fw[4], fx[8];
+        read_frags(s_, fw, fx);                                   // L(s): fragments of stage s ...
+        if (s_ >= 1 && s_ + 3 < nt) stage(s_ + 3);                // ... refill the buffer of stage s-1 ...
+        // ... and settle my pieces of stage s+1 (stages s+2, s+3 are younger; so are the previous tile's 16 stores
+        // until the first in-loop stage, issued behind them, is the one waited for)
+        if (s_ < 3 && stores_pending) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (s_ + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (s_ + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        mma_rows(fw, fx, 0, 8);                                   // M(s): the matrix pipe is this wave's alone
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
     }
-    step(nt - 2, fwA, fxA, fwB, fxB);  // fetches the last stage; its wait is vmcnt(0)
-    mma_rows(fwB, fxB, 0, 8);
 
     // ---- next tile's prologue, then this tile's epilogue ----
     const uint32_t next = tile + gridDim.x;
     const bool has_next = next < n_tiles;
-    __builtin_amdgcn_s_barrier();   // every wave has read the last stage: the ring is free
+    // every wave has read the last stage: the ring is free (ping-pong: the early half waits for the late half)
+    if (PP == 0 || wm == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (has_next) {
       locate(next);
@@ -949,18 +1095,9 @@ __device__ __forceinline__ f32x4 mma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 // of up to 3e-8.  The weight operand is therefore scaled by 2^6 on the fly (nn.Linear weights are O(1e-2); the
 // accumulators are scaled back exactly in the epilogue) and the variant is only used where the caller vouches for
 // activations that are bounded by construction (f32_gemm = 2 of aurora_hip_linear_ex: LayerNorm outputs and their GELU'd linears).
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 struct Split2 { u32x4 h, l; };
 
-__device__ __forceinline__ void split_pair_f16(float a0, float a1, uint32_t& h, uint32_t& l) {
-  const f32x2_t v = {a0, a1};
-  const f16x2_t hh = __builtin_convertvector(v, f16x2_t);             // v_cvt_pk_f16_f32 (round to nearest even)
-  const f32x2_t r = v - __builtin_convertvector(hh, f32x2_t);         // exact
-  h = __builtin_bit_cast(uint32_t, hh);
-  l = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
-}
 template <bool SCALE>
 __device__ __forceinline__ Split2 split8_f16(u32x4 a, u32x4 b) {
   constexpr float S = SCALE ? 64.0f : 1.0f;
@@ -1133,6 +1270,230 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
   epilogue_256<float>(p, acc, m0, n0, wm, wn, i16, g);
 }
 
+
+// =================================================================================================
+// fp32 linears by two fp16 terms, ping-pong form: 128 x 256 tile, whole-line K-stages, three-stage ring.
+//
+// linear_kernel_256_f32x3<2> above runs all eight waves in phase through "read fragments, split, 96 MFMAs" with one
+// barrier and a full drain (vmcnt(0)) per K = 32: the two waves of a SIMD fight over its matrix pipe and its VALU issue
+// (the split costs ~240 VALU instructions per wave and K = 32 against 96 MFMAs), and the kernel sits at 290 TFLOP/s
+// fp32-equivalent = 0.87 PFLOP/s of fp16 MFMA work where the bf16 kernels reach 1.15-1.4.  The ping-pong schedule of
+// linear_kernel_256pp needs every LDS read of a stage inside the LOAD phase (the partner's DMA refills the ring during
+// the MATRIX phase) and a ring at least three K-steps deep; fp32 operands of a 256 x 256 tile are 64 KiB per K = 32,
+// i.e. two steps.  Hence this geometry:
+//   * tile 128 x 256, 8 waves as 2 (m) x 4 (n), wave tile 64 x 64 = 4 x 4 fragments (64 accumulator registers);
+//   * a K-stage is 128 BYTES of every operand row (32 fp32 = one fp16 MFMA of K = 32): 16 KiB of activations + 32 KiB of
+//     weights, staged by LDS-DMA in whole cache lines (8 rows x 128 B per wave instruction -- the pattern the vector
+//     memory front end moves 4x faster than 16 rows x 64 B), XOR-swizzled as in the 128 x 128 kernel; 3 stages = 144 KiB;
+//   * L(s): 16 fragment reads (raw fp32: 32 registers of activations; the weights are split to fp16 pairs at once),
+//     DMA of stage s+2, counted wait for the wave's pieces of stage s+1;  M(s): per activation fragment one split
+//     (20 VALU) + 12 MFMAs, the VALU work overlapping the wave's own matrix instructions;
+//   * waves 4-7 run one phase behind waves 0-3 (one extra barrier in front, one behind for the others): a SIMD's matrix
+//     pipe always belongs to exactly one wave.
+// Same range contract and guard as the kernel above (which remains the fallback for K % 32 != 0).
+// =================================================================================================
+constexpr int VM = 128, VN = 256, VROW = 128, VTHREADS = 512, VNST = 3;
+constexpr int VOPER_X = VM * VROW, VOPER_W = VN * VROW, VSTAGE = VOPER_X + VOPER_W;   // 16 + 32 = 48 KiB
+
+template <bool A_PRE, bool W_PRE>   // operand already in the fp16-pair layout: its split (all of its VALU work) disappears
+__global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.guard != nullptr && !(*p.guard < p.guard_limit)) return;   // guarded launch: the three-term kernel does the work
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // waves w and w+4 share a SIMD; wm = 1 runs one phase behind
+
+  uint32_t tile_m, tile_n;
+  tile_of_block(blockIdx.x, (uint32_t)p.n_blocks, (uint32_t)(p.n_blocks / p.tiles_n), (uint32_t)p.tiles_n, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * VM;
+  const int n0 = (int)tile_n * VN;
+
+  const char* src_x[2];
+  const char* src_w[4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int id = r * VTHREADS + tid;
+    const int row = id >> 3, c = id & 7;
+    int64_t gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    src_x[r] = p.A + gm * p.lda_b + ((c ^ swz_x(row)) << 4);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int id = r * VTHREADS + tid;
+    const int row = id >> 3, c = id & 7;
+    src_w[r] = p.W + (int64_t)(n0 + row) * p.ldw_b + ((c ^ swz_w(row)) << 4);
+  }
+  auto stage = [&](int kt) {
+    const int64_t koff = (int64_t)kt * VROW;
+    char* base = smem + (kt % VNST) * VSTAGE;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)   // wave-uniform LDS address; the hardware adds lane * 16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[r] + koff),
+                                       (lds_ptr_t)(base + (r * VTHREADS + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
+                                       (lds_ptr_t)(base + VOPER_X + (r * VTHREADS + wave * 64) * 16), 16, 0, 0);
+  };
+  // fragment read offsets.  Lane group g multiplies k = 8g..8g+7 of the stage: as fp32 that is chunks 2g and 2g + 1 of the
+  // row, in the fp16-pair layout chunk g (high halves) and chunk g + 4 (remainders) -- the same k order either way, so
+  // an operand may arrive split or not without changing a bit of the result.
+  const int i16 = lane & 15, g = lane >> 4;
+  int off_x[4][2], off_w[4][2];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int row_x = wm * 64 + 16 * f + i16;
+    const int row_w = wn * 64 + 16 * (i16 >> 2) + 4 * f + (i16 & 3);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int cx = A_PRE ? g + 4 * ks : 2 * g + ks, cw = W_PRE ? g + 4 * ks : 2 * g + ks;
+      off_x[f][ks] = row_x * VROW + ((cx ^ swz_x(row_x)) << 4);
+      off_w[f][ks] = VOPER_X + row_w * VROW + ((cw ^ swz_w(row_w)) << 4);
+    }
+  }
+  f32x4 acc[4][4];  // [fn][fm]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.k_tiles;   // K / 32, >= 3 (dispatch)
+  stage(0);
+  stage(1);
+  stage(2);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // stage 0 is complete
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
+
+  for (int s = 0; s < nt; ++s) {
+    // ---- L(s) ----
+    const char* buf = smem + (s % VNST) * VSTAGE;
+    u32x4 xa[4], xb[4];
+    Split2 w[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      xa[f] = *reinterpret_cast<const u32x4*>(buf + off_x[f][0]);
+      xb[f] = *reinterpret_cast<const u32x4*>(buf + off_x[f][1]);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+      if constexpr (W_PRE)   // chunk g = high halves of k = 8g..8g+7, chunk g + 4 = their remainders
+        w[f] = Split2{*reinterpret_cast<const u32x4*>(buf + off_w[f][0]), *reinterpret_cast<const u32x4*>(buf + off_w[f][1])};
+      else
+        w[f] = split8_f16<true>(*reinterpret_cast<const u32x4*>(buf + off_w[f][0]), *reinterpret_cast<const u32x4*>(buf + off_w[f][1]));
+    if (s >= 1 && s + 2 < nt) stage(s + 2);   // into the buffer of stage s-1
+    if (s + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // own pieces of stage s+1 have landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    // ---- M(s): smallest terms first; consecutive MFMAs go to different accumulators ----
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+      Split2 x;
+      if constexpr (A_PRE) x = Split2{xa[fm], xb[fm]};
+      else x = split8_f16<false>(xa[fm], xb[fm]);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_f16(w[fn].l, x.h, acc[fn][fm]);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_f16(w[fn].h, x.l, acc[fn][fm]);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = mma_f16(w[fn].h, x.h, acc[fn][fm]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // the early half waits for the late half's last phase
+  asm volatile("" ::: "memory");
+
+  // ---- epilogue: lane owns row m (per fm) x 16 consecutive features; undo the 2^6 weight scale (exact) ----
+  const int nbase = n0 + wn * 64 + 16 * g;
+  float bias_v[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
+  const bool vec = p.vec_store != 0;
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const int64_t m = m0 + wm * 64 + 16 * fm + i16;
+    if (m >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      v[4 * fn + 0] = fmaf(acc[fn][fm].x, 0.015625f, bias_v[4 * fn + 0]);
+      v[4 * fn + 1] = fmaf(acc[fn][fm].y, 0.015625f, bias_v[4 * fn + 1]);
+      v[4 * fn + 2] = fmaf(acc[fn][fm].z, 0.015625f, bias_v[4 * fn + 2]);
+      v[4 * fn + 3] = fmaf(acc[fn][fm].w, 0.015625f, bias_v[4 * fn + 3]);
+    }
+    if (p.act == AURORA_ACT_GELU || p.act == ACT_GELU_FAST) {
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        const f32x2_hw r = gelu_erf_fast2(f32x2_hw{v[t], v[t + 1]});
+        v[t] = r.x;
+        v[t + 1] = r.y;
+      }
+    } else if (p.act == AURORA_ACT_SILU) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
+    }
+    if (p.res) {
+      const float* rp = p.res + m * p.ldr + nbase;
+      if (vec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 rv = reinterpret_cast<const f32x4*>(rp)[q];
+          v[4 * q] += rv.x; v[4 * q + 1] += rv.y; v[4 * q + 2] += rv.z; v[4 * q + 3] += rv.w;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] += rp[t];
+      }
+    }
+    if (p.out_split) {
+      // fp16-pair layout: the 16 features nbase.. are halves (nbase % 32) .. +15 of group nbase / 32 -- 32 bytes of high
+      // halves, and 32 bytes of remainders 64 bytes further on
+      uint32_t h[8], l[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) split_pair_f16(v[2 * t], v[2 * t + 1], h[t], l[t]);
+      char* dst = p.C + (m * p.ldc + (nbase & ~31)) * 4 + (nbase & 31) * 2;
+      reinterpret_cast<u32x4*>(dst)[0] = u32x4{h[0], h[1], h[2], h[3]};
+      reinterpret_cast<u32x4*>(dst)[1] = u32x4{h[4], h[5], h[6], h[7]};
+      reinterpret_cast<u32x4*>(dst + 64)[0] = u32x4{l[0], l[1], l[2], l[3]};
+      reinterpret_cast<u32x4*>(dst + 64)[1] = u32x4{l[4], l[5], l[6], l[7]};
+      continue;
+    }
+    store16<float>(reinterpret_cast<float*>(p.C) + m * p.ldc + nbase, v, vec, 16);
+    if (p.C2) store16<bf16_t>(reinterpret_cast<bf16_t*>(p.C2) + m * p.ldc2 + nbase, v, vec, 16);
+  }
+}
+
+// fp32 rows -> the fp16-pair layout the two-term kernels can take directly: per 32 features 128 bytes, the 32 fp16 high
+// halves  h = fp16(s x)  followed by the 32 remainders  l = fp16(s x - h).  One lane per 8 features.
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, int64_t ld_src, char* __restrict__ dst,
+                                                        int64_t ld_dst, int64_t rows, int K, float scale) {
+  const int per_row = K >> 3;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= rows * per_row) return;
+  const int64_t r = id / per_row;
+  const int c = (int)(id - r * per_row) * 8;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(src + r * ld_src + c);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(src + r * ld_src + c + 4);
+  uint32_t h[4], l[4];
+  split_pair_f16(a.x * scale, a.y * scale, h[0], l[0]);
+  split_pair_f16(a.z * scale, a.w * scale, h[1], l[1]);
+  split_pair_f16(b.x * scale, b.y * scale, h[2], l[2]);
+  split_pair_f16(b.z * scale, b.w * scale, h[3], l[3]);
+  char* d = dst + (r * ld_dst + (c & ~31)) * 4 + (c & 31) * 2;
+  *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<u32x4*>(d + 64) = u32x4{l[0], l[1], l[2], l[3]};
+}
+
 }  // namespace
 
 }  // namespace aurora
@@ -1167,9 +1528,20 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
                                     int dtype, int act, int f32_gemm, const float* guard, float guard_limit,
                                     void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "linear: bad dtype %d", dtype);
+  const int pre = f32_gemm < 0 ? 0 : f32_gemm & (AURORA_F32_A_SPLIT | AURORA_F32_W_SPLIT | AURORA_F32_C_SPLIT);
+  if (pre) f32_gemm &= ~pre;
   AURORA_CHECK_ARG(f32_gemm >= -1 && f32_gemm <= 2, "linear: bad fp32 GEMM mode %d", f32_gemm);
   const int mode = f32_gemm < 0 ? default_f32_mode() : f32_gemm;
-  const float* const g_guard = mode == 2 ? guard : nullptr;
+  // pre-split operands / output: the two-term ping-pong kernel only.  An A-split launch cannot fall back to three terms
+  // (they need the fp32 values), so it takes no guard; a W-split launch with a guard runs iff the guard holds and the
+  // caller pairs it with a mode-1 launch on the fp32 weights carrying the same guard, which runs iff it does not.
+  AURORA_CHECK_ARG(!pre || (dtype == AURORA_F32 && mode == 2 && N % VN == 0 && K % 32 == 0 && K >= 96),
+                   "linear: fp16-pair operands need fp32, mode 2, N %% 256 == 0, K %% 32 == 0, K >= 96 (N=%d K=%d)", N, K);
+  AURORA_CHECK_ARG(!(pre & AURORA_F32_A_SPLIT) || ((pre & AURORA_F32_W_SPLIT) && guard == nullptr),
+                   "linear: a pre-split activation operand needs pre-split weights and takes no guard");
+  AURORA_CHECK_ARG(!(pre & AURORA_F32_C_SPLIT) || (C2 == nullptr && ldc % 32 == 0 && ((uintptr_t)C % 16) == 0),
+                   "linear: fp16-pair output needs ldc %% 32 == 0, 16-byte alignment and no second output");
+  const float* const g_guard = (mode == 2 || (mode == 1 && dtype == AURORA_F32)) ? guard : nullptr;
   const float g_guard_limit = guard_limit;
   AURORA_CHECK_ARG(M > 0 && N > 0 && K > 0, "linear: empty problem M=%lld N=%d K=%d", (long long)M, N, K);
   const int es = dtype == AURORA_F32 ? 4 : 2, es2 = dtype == AURORA_F32 ? 2 : 4;
@@ -1232,6 +1604,7 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
   if (split && big && act == AURORA_ACT_GELU) p.act = ACT_GELU_FAST;
   p.guard = split ? g_guard : nullptr;
   p.guard_limit = g_guard_limit;
+  p.out_split = (pre & AURORA_F32_C_SPLIT) ? 1 : 0;
   AURORA_CHECK_ARG(p.n_blocks < (int64_t)1 << 31, "linear: too many tiles");
 
   dim3 grid((unsigned)p.n_blocks);
@@ -1244,39 +1617,75 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 2, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<1>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
     attr_done = true;
   }
+  // two fp16 terms: the ping-pong kernel (128 x 256 tiles, K-stages of 32) when K allows; AURORA_F32_VARIANT=0 keeps the
+  // in-phase 256 x 256 kernel for A/B
+  static const int f32_variant = [] { const char* e = getenv("AURORA_F32_VARIANT"); return e ? atoi(e) : 1; }();
+  const bool f32pp = big && split && mode == 2 && (f32_variant == 1 || pre) && K % 32 == 0 && K >= 96;
+  auto launch_f32pp = [&]() {
+    LinearArgs q = p;
+    q.k_tiles = K / 32;
+    q.tiles_n = N / VN;
+    q.n_blocks = ((M + VM - 1) / VM) * q.tiles_n;
+    const dim3 g((unsigned)q.n_blocks), b(VTHREADS);
+    if (pre & AURORA_F32_A_SPLIT) hipLaunchKernelGGL((linear_kernel_f32pp<true, true>), g, b, VNST * VSTAGE, as_stream(stream), q);
+    else if (pre & AURORA_F32_W_SPLIT) hipLaunchKernelGGL((linear_kernel_f32pp<false, true>), g, b, VNST * VSTAGE, as_stream(stream), q);
+    else hipLaunchKernelGGL((linear_kernel_f32pp<false, false>), g, b, VNST * VSTAGE, as_stream(stream), q);
+  };
   if (mid) {
     hipLaunchKernelGGL((linear_kernel_256<bf16_t, 2, 3, 0>), grid, dim3(256), MID_LDS, as_stream(stream), p);
   } else if (big) {
-    if (split && mode == 2 && g_guard != nullptr) {   // both variants; the device word picks one
-      hipLaunchKernelGGL(linear_kernel_256_f32x3<2>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    if (pre) {
+      launch_f32pp();
+    } else if (split && mode == 1 && g_guard != nullptr) {   // the three-term half of a guarded pair (see above)
       hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-    } else if (split && mode == 2)
+    } else if (split && mode == 2 && g_guard != nullptr) {   // both variants; the device word picks one
+      if (f32pp) launch_f32pp();
+      else hipLaunchKernelGGL(linear_kernel_256_f32x3<2>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+      hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    } else if (f32pp)
+      launch_f32pp();
+    else if (split && mode == 2)
       hipLaunchKernelGGL(linear_kernel_256_f32x3<2>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (split)
       hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (dtype == AURORA_F32)
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else {
-      static const int variant = [] { const char* e = getenv("AURORA_GEMM_VARIANT"); return e ? atoi(e) : 4; }();
-      // Persistent form where it wins (measured, profiles/r02_ab_gemm_variants.log: +3..6 % for N >= 1024 and K <= 2048,
-      // -1..4 % on the long-K / two-n-tile shapes, whose tiles spend little of their time outside the main loop).
-      // AURORA_GEMM_VARIANT: 0 ring kernel, 1 ring + static wave priority, 2 / 3 the same with the persistent form
-      // wherever it is legal (A/B), default 4 = 3 under the shape rule.
+      static const int variant = [] { const char* e = getenv("AURORA_GEMM_VARIANT"); return e ? atoi(e) : 8; }();
+      // AURORA_GEMM_VARIANT (A/B switch, profiles/r02_ab_gemm_variants.log):
+      //   8 (default) ping-pong main loop; persistent form of it where that wins (N >= 1024 and K <= 2048: +3..8 %;
+      //     the long-K / two-n-tile shapes spend little of a tile outside the main loop and lose 1-2 % to it)
+      //   7 ping-pong, persistent wherever legal      5 ping-pong, never persistent
+      //   4 in-phase ring kernel + static wave priority, persistent by the same shape rule (round 2's first default)
+      //   3 / 2 in-phase, persistent wherever legal, with / without priority      1 / 0 in-phase ring kernel with / without
       const bool plain = C2 == nullptr && residual == nullptr && vec && N % BN2 == 0 && p.k_tiles >= 8;
       const bool wins = N >= 1024 && K <= 2048;
-      if (variant >= 2 && plain && p.n_blocks > device_cus() && (variant != 4 || wins)) {
-        const dim3 pgrid((unsigned)device_cus());   // one workgroup per CU walks over the tiles
+      const bool many = p.n_blocks > device_cus();
+      const dim3 pgrid((unsigned)device_cus());   // persistent kernels: one workgroup per CU walks over the tiles
+      if (variant >= 7 && plain && many && (variant == 7 || wins))
+        hipLaunchKernelGGL((linear_kernel_256p<0, 1>), pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
+      else if ((variant >= 7 || variant == 5) && p.k_tiles >= 4)
+        hipLaunchKernelGGL(linear_kernel_256pp<0>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+      else if (variant == 6 && p.k_tiles >= 4)
+        hipLaunchKernelGGL(linear_kernel_256pp<1>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+      else if (variant >= 2 && variant <= 4 && plain && many && (variant != 4 || wins)) {
         if (variant == 2)
-          hipLaunchKernelGGL(linear_kernel_256p<0>, pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
+          hipLaunchKernelGGL((linear_kernel_256p<0, 0>), pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
         else
-          hipLaunchKernelGGL(linear_kernel_256p<1>, pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
-      } else if (variant == 1 || variant >= 3)
+          hipLaunchKernelGGL((linear_kernel_256p<1, 0>), pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
+      } else if (variant == 1 || variant == 3 || variant == 4)
         hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4, 1>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
       else
         hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
@@ -1288,4 +1697,15 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
       hipLaunchKernelGGL(linear_kernel<bf16_t>, grid, dim3(THREADS), 4 * TILE_BYTES, as_stream(stream), p);
   }
   return check_launch("linear");
+}
+
+extern "C" int aurora_hip_split_f16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int K,
+                                    float scale, void* stream) {
+  AURORA_CHECK_ARG(src != nullptr && dst != nullptr && rows > 0 && K > 0 && K % 32 == 0, "split_f16: K=%d must be a positive multiple of 32", K);
+  AURORA_CHECK_ARG(ld_src >= K && ld_dst >= K && ld_src % 4 == 0 && ld_dst % 32 == 0 && ((uintptr_t)src % 16) == 0 &&
+                   ((uintptr_t)dst % 16) == 0, "split_f16: strides / alignment");
+  const int64_t n = rows * (K >> 3);
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), src, ld_src,
+                     (char*)dst, ld_dst, rows, K, scale);
+  return check_launch("split_f16");
 }

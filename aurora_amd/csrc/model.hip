@@ -220,8 +220,12 @@ struct Resampler {
     int inner, head_dim, hidden, dim;
     float v_l1;
     int f16_mode;   // fp32 GEMM mode of this layer's bounded linears: 2 (two fp16 terms) when weights / LN bounds allow
+    // the same weights in the fp16-pair layout, scaled by 2^6 (null where mode or shape rule it out): the two-term GEMMs
+    // then spend no VALU work on the weight operand, and none at all where the activations arrive split as well
+    const void *to_kv_s = nullptr, *to_out_s = nullptr, *fc1_s = nullptr, *fc2_s = nullptr;
   };
   std::vector<Layer> layers;
+  std::vector<DevBuf> own;
 };
 struct DevTables { DevBuf tok, grp; int n_windows = 0, n_tok = 0; bool has_grp = false; };
 
@@ -473,6 +477,22 @@ Resampler pack_resampler(Model& m, const std::string& prefix, int depth, int hea
       w_max = std::max(w_max, absmax_of(p + nm));
     const float ln_bound = absmax_of(p + ".2.weight") * sqrtf((float)l.dim) + absmax_of(p + ".2.bias");
     l.f16_mode = (w_max < 1000.f && ln_bound < F16_SAFE) ? bounded_mode() : -1;
+    if (l.f16_mode == 2 && getenv("AURORA_NO_PRESPLIT") == nullptr) {
+      auto presplit = [&](const std::string& name) -> const void* {
+        const Tensor& t = m.T_(name);
+        const int64_t N = t.shape[0], K = t.shape[1];
+        if (N % 256 != 0 || K % 32 != 0 || K < 96) return nullptr;
+        r.own.emplace_back((size_t)N * K * 4);
+        if (aurora_hip_split_f16(t.f(), K, r.own.back().p, K, N, (int)K, 64.0f, nullptr) != AURORA_OK)
+          throw std::runtime_error(aurora_hip_last_error());
+        return r.own.back().p;
+      };
+      l.to_kv_s = presplit(p + ".0.to_kv.weight");
+      l.to_out_s = presplit(p + ".0.to_out.weight");
+      l.fc1_s = presplit(p + ".1.net.0.weight");
+      l.fc2_s = presplit(p + ".1.net.2.weight");
+      hip_ok(hipDeviceSynchronize(), "split weights");
+    }
     r.layers.push_back(l);
   }
   return r;
@@ -499,8 +519,19 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     float* y = (float*)m.arena.take((size_t)n_rows * Dd * 4);
     const size_t after_y = m.arena.top;
     float* kv = (float*)m.arena.take((size_t)ctx_rows * 2 * inner * 4);
-    L.linear(ctx, ctx_dim, ly.to_kv, ctx_dim, nullptr, kv, 2 * inner, ctx_rows, 2 * inner, ctx_dim, AURORA_F32, 0, nullptr, 0,
-             nullptr, 0, ly.f16_mode, ctx_max, F16_SAFE);
+    // guarded linears with pre-split weights: the two-term launch runs iff the guard holds, the three-term one (fp32
+    // weights) iff it does not
+    auto guarded = [&](const float* A, int64_t lda, const float* Wf, const void* Ws, float* C_, int64_t ldc, int64_t M_, int N_,
+                       int K_, float limit) {
+      if (Ws) {
+        L.linear(A, lda, Ws, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, 2 | AURORA_F32_W_SPLIT,
+                 ctx_max, limit);
+        L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, 1, ctx_max, limit);
+      } else {
+        L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, ly.f16_mode, ctx_max, limit);
+      }
+    };
+    guarded(ctx, ctx_dim, ly.to_kv, ly.to_kv_s, kv, 2 * inner, ctx_rows, 2 * inner, ctx_dim, F16_SAFE);
     if (ly.ln_k_w)   // LayerNorm over the K half, in place (perceiver.py:144-147)
       L.layernorm(kv, 2 * inner, ly.ln_k_w, ly.ln_k_b, nullptr, 0, 0, kv, 2 * inner, nullptr, 0, ctx_rows, inner, 1e-5f,
                   AURORA_F32);
@@ -518,17 +549,34 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
                                         AURORA_F32, L.stream); });
     float* o = (float*)m.arena.take((size_t)n_rows * Dd * 4);
     // |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
-    L.linear(att, inner, ly.to_out, inner, nullptr, o, Dd, n_rows, Dd, inner, AURORA_F32, 0, nullptr, 0, nullptr, 0, ly.f16_mode, ctx_max,
-             F16_SAFE / ly.v_l1);
+    guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, F16_SAFE / ly.v_l1);
     float* lat1 = (float*)m.arena.take((size_t)n_rows * Dd * 4);
-    if (i == 0) L.layernorm(o, Dd, ly.ln1_w, ly.ln1_b, latents0, Dd, Lq, lat1, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
-    else L.layernorm(o, Dd, ly.ln1_w, ly.ln1_b, lat, Dd, 0, lat1, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
+    // The MLP in the fp16-pair layout end to end: the LayerNorm writes its result a second time already split, fc1 reads
+    // that and writes its GELU'd result split (nothing else reads it), fc2 reads that -- neither GEMM splits anything.
+    const bool pairs = ly.fc1_s && ly.fc2_s && Dd % 32 == 0;
+    float* lat1_s = pairs ? (float*)m.arena.take((size_t)n_rows * Dd * 4) : nullptr;
+    {
+      const float* res_ = i == 0 ? latents0 : lat;
+      const int64_t mod_ = i == 0 ? Lq : 0;
+      if (pairs)
+        timed(m, L.stream, K_LAYERNORM, 0.0, [&] {
+          return aurora_hip_layernorm_split(o, Dd, ly.ln1_w, ly.ln1_b, res_, Dd, mod_, lat1, Dd, lat1_s, Dd, n_rows, Dd, eps, L.stream);
+        });
+      else L.layernorm(o, Dd, ly.ln1_w, ly.ln1_b, res_, Dd, mod_, lat1, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
+    }
     float* hid = (float*)m.arena.take((size_t)n_rows * ly.hidden * 4);
     // fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU: bounded whatever the inputs are
-    L.linear(lat1, Dd, ly.fc1_w, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
-             nullptr, 0, ly.f16_mode);
-    L.linear(hid, ly.hidden, ly.fc2_w, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0,
-             ly.f16_mode);
+    if (pairs) {
+      const int all = 2 | AURORA_F32_A_SPLIT | AURORA_F32_W_SPLIT;
+      L.linear(lat1_s, Dd, ly.fc1_s, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
+               nullptr, 0, all | AURORA_F32_C_SPLIT);
+      L.linear(hid, ly.hidden, ly.fc2_s, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0, all);
+    } else {
+      L.linear(lat1, Dd, ly.fc1_w, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
+               nullptr, 0, ly.f16_mode);
+      L.linear(hid, ly.hidden, ly.fc2_w, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0,
+               ly.f16_mode);
+    }
     L.layernorm(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, y, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
     m.arena.top = after_y;            // temporaries of this layer are dead (a previous layer's result stays below y)
     lat = y;

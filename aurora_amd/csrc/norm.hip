@@ -42,6 +42,7 @@ struct LnArgs {
   const float* res; int64_t ldr; int64_t res_mod;
   float* out_f32; int64_t ldo; void* out_t; int64_t ldt;
   int64_t M; int D; float eps;
+  int split_t;   // fp32 kernel: out_t receives the fp16-pair layout of the two-term GEMMs (aurora_hip_layernorm_split)
 };
 
 template <typename T, int MAXC>
@@ -141,7 +142,17 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
         for (int j = 0; j < 4; ++j) o[j] += r4[j];
       }
       if (p.out_f32) store4(p.out_f32 + row * p.ldo + e, o);
-      if (p.out_t) store4(reinterpret_cast<float*>(p.out_t) + row * p.ldt + e, o);
+      if (p.out_t && p.split_t) {
+        // features e..e+3 of group e / 32: four high halves (8 bytes), their remainders 64 bytes further on
+        uint32_t h0, h1, l0, l1;
+        split_pair_f16(o[0], o[1], h0, l0);
+        split_pair_f16(o[2], o[3], h1, l1);
+        char* d = reinterpret_cast<char*>(p.out_t) + (row * p.ldt + (e & ~31)) * 4 + (e & 31) * 2;
+        *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(d + 64) = u32x2{l0, l1};
+      } else if (p.out_t) {
+        store4(reinterpret_cast<float*>(p.out_t) + row * p.ldt + e, o);
+      }
     }
   }
 }
@@ -248,10 +259,30 @@ using namespace aurora;
     else hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__);                                             \
   } while (0)
 
+static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const float* shift, const float* res, int64_t ldr,
+                          int64_t res_mod, float* out_f32, int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D,
+                          float eps, int dtype, int split_t, void* stream);
+
 extern "C" int aurora_hip_layernorm(const void* y, int64_t ldy, const float* gain, const float* shift,
                                     const float* res, int64_t ldr, int64_t res_mod, float* out_f32,
                                     int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D, float eps,
                                     int dtype, void* stream) {
+  return layernorm_impl(y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps, dtype, 0, stream);
+}
+
+extern "C" int aurora_hip_layernorm_split(const float* y, int64_t ldy, const float* gain, const float* shift,
+                                          const float* res, int64_t ldr, int64_t res_mod, float* out_f32,
+                                          int64_t ldo, void* out_split, int64_t ld_split, int64_t M, int D, float eps,
+                                          void* stream) {
+  AURORA_CHECK_ARG(out_split != nullptr && D % 32 == 0 && ld_split % 32 == 0 && ld_split >= D,
+                   "layernorm_split: D=%d and the pair-layout stride must be multiples of 32", D);
+  return layernorm_impl(y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_split, ld_split, M, D, eps, AURORA_F32, 1,
+                        stream);
+}
+
+static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const float* shift, const float* res, int64_t ldr,
+                          int64_t res_mod, float* out_f32, int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D,
+                          float eps, int dtype, int split_t, void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "layernorm: bad dtype");
   AURORA_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 4096, "layernorm: D=%d must be a multiple of 8, <= 4096", D);
   const int es = dtype == AURORA_F32 ? 4 : 2;
@@ -262,7 +293,7 @@ extern "C" int aurora_hip_layernorm(const void* y, int64_t ldy, const float* gai
                    "layernorm: unaligned residual/output rows");
   AURORA_CHECK_ARG(out_f32 || out_t, "layernorm: no output");
   if (M <= 0) return AURORA_OK;
-  LnArgs p{y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps};
+  LnArgs p{y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps, split_t};
   if (dtype == AURORA_F32) {
     const dim3 grid(row_blocks(M)), block(256);
     if (D <= 256) hipLaunchKernelGGL(layernorm_f32_kernel<1>, grid, block, 0, as_stream(stream), p);

@@ -55,6 +55,9 @@ _SIGNATURES = {
                                      c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                      c_int, c_int, c_void_p, c_float, c_void_p]),
     "aurora_hip_absmax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "aurora_hip_split_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
+    "aurora_hip_layernorm_split": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                           c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
     "aurora_hip_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                   c_int, c_void_p]),
@@ -257,10 +260,25 @@ class bounded_activations(f32_gemm):
         _f32.state = self.prev if explicit else self.state
 
 
+F32_A_SPLIT, F32_W_SPLIT, F32_C_SPLIT = 4, 8, 16   # include/aurora_hip.h: operands / output in the fp16-pair layout
+
+
+def split_f16(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 rows -> the fp16-pair layout of the two-term GEMMs (same shape, dtype float32 as a container: per 32
+    features 32 high halves, then 32 remainders).  Weights take scale = 64."""
+    assert x.dtype == torch.float32 and x.dim() == 2
+    ld, K = _rows(x)
+    out = torch.empty_like(x, memory_format=torch.contiguous_format) if out is None else out
+    ldo, _ = _rows(out)
+    _check(load().aurora_hip_split_f16(_ptr(x), ld, _ptr(out), ldo, x.shape[0], K, scale, _stream()))
+    return out
+
+
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
            out2: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           act: int = ACT_NONE, n: Optional[int] = None, k: Optional[int] = None) -> torch.Tensor:
-    """out[M, N] = act(a[M, K] @ w[N, K].T + bias) (+ residual); all 2-D row-major views."""
+           act: int = ACT_NONE, n: Optional[int] = None, k: Optional[int] = None, presplit: int = 0) -> torch.Tensor:
+    """out[M, N] = act(a[M, K] @ w[N, K].T + bias) (+ residual); all 2-D row-major views.
+    `presplit`: F32_* flags -- which of a / w / out are in the fp16-pair layout (two-term mode only)."""
     lda, ka = _rows(a)
     ldw, kw = _rows(w)
     K = k if k is not None else ka
@@ -280,6 +298,8 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
     name = "linear_bf16" if a.dtype == torch.bfloat16 else "linear_f32"
     with _Timed(name, 2.0 * M * N * K):  # algorithmic FLOPs
         mode, guard, limit = _f32_state()
+        if presplit:
+            mode = 2 | presplit
         _check(load().aurora_hip_linear_ex(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), _ptr(out), ldc, _ptr(out2),
                                            ldc2, _ptr(residual), ldr, M, N, K, dtype_code(a.dtype), act,
                                            mode, _ptr(guard), limit, _stream()))
@@ -309,7 +329,8 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], out: t
 def layernorm(y: torch.Tensor, gain: Optional[torch.Tensor], shift: Optional[torch.Tensor], *,
               res: Optional[torch.Tensor] = None, res_mod: int = 0,
               out_f32: Optional[torch.Tensor] = None, out_t: Optional[torch.Tensor] = None,
-              eps: float = 1e-5, d: Optional[int] = None) -> None:
+              eps: float = 1e-5, d: Optional[int] = None, split_t: bool = False) -> None:
+    """`split_t`: fp32 rows only -- `out_t` receives the fp16-pair layout (aurora_hip_layernorm_split)."""
     ldy, dy = _rows(y)
     D = d if d is not None else dy
     M = y.shape[0]
@@ -327,6 +348,12 @@ def layernorm(y: torch.Tensor, gain: Optional[torch.Tensor], shift: Optional[tor
         ldt, _ = _rows(out_t)
     nbytes = M * D * (y.element_size() + (4 if res is not None else 0) + (4 if out_f32 is not None else 0)
                       + (y.element_size() if out_t is not None else 0))
+    if split_t:
+        assert y.dtype == torch.float32 and out_t is not None
+        with _Timed("layernorm", float(nbytes)):
+            _check(load().aurora_hip_layernorm_split(_ptr(y), ldy, _ptr(gain), _ptr(shift), _ptr(res), ldr, res_mod,
+                                                     _ptr(out_f32), ldo, _ptr(out_t), ldt, M, D, eps, _stream()))
+        return
     with _Timed("layernorm", float(nbytes)):
         _check(load().aurora_hip_layernorm(_ptr(y), ldy, _ptr(gain), _ptr(shift), _ptr(res), ldr, res_mod,
                                            _ptr(out_f32), ldo, _ptr(out_t), ldt, M, D, eps,

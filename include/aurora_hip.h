@@ -76,6 +76,25 @@ int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, int64_t ldw,
                          int f32_gemm, const float* guard, float guard_limit, void* stream);
 int aurora_hip_default_f32_gemm(void);
 
+/* Mode 2 with operands that are ALREADY split (flags OR-ed into f32_gemm = 2): the split is the same arithmetic wherever
+ * it happens, so results are bit-identical to plain mode 2, but a GEMM whose operands arrive split spends no VALU work
+ * on them -- the two-term kernel goes from 0.29 to 0.40 PFLOP/s fp32-equivalent when both do.
+ * The fp16-pair layout of a row of K fp32 values (K % 32 == 0) occupies the same K * 4 bytes: per group of 32 features
+ * 128 bytes, first the 32 fp16 high halves h = fp16(x), then the 32 fp16 remainders l = fp16(x - h); strides stay in
+ * 4-byte units.  aurora_hip_split_f16 produces it (weights: scale = 64, the 2^6 of mode 2), aurora_hip_layernorm_split
+ * and a linear with AURORA_F32_C_SPLIT write it directly.
+ *   AURORA_F32_W_SPLIT: W is in the pair layout, scaled by 64.  With a guard the launch runs iff *guard < guard_limit
+ *     and has NO fallback of its own: pair it with an f32_gemm = 1 call on the fp32 weights carrying the same guard
+ *     (mode 1 with a guard runs iff the guard FAILS).
+ *   AURORA_F32_A_SPLIT: A is in the pair layout (unscaled); needs AURORA_F32_W_SPLIT, takes no guard.
+ *   AURORA_F32_C_SPLIT: C is written in the pair layout (after bias / activation / residual); ldc % 32 == 0, no C2.
+ * Shapes: N % 256 == 0, K % 32 == 0, K >= 96. */
+#define AURORA_F32_A_SPLIT 4
+#define AURORA_F32_W_SPLIT 8
+#define AURORA_F32_C_SPLIT 16
+int aurora_hip_split_f16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int K,
+                         float scale, void* stream);
+
 /* out[0] = max |x[i]| over n contiguous fp32 values (x 16-byte aligned); NaNs are ignored. */
 int aurora_hip_absmax(const float* x, int64_t n, float* out, void* stream);
 
@@ -112,6 +131,13 @@ int aurora_hip_layernorm(const void* y, int64_t ldy, const float* gain, const fl
                          const float* res, int64_t ldr, int64_t res_mod,
                          float* out_f32, int64_t ldo, void* out_t, int64_t ldt,
                          int64_t M, int D, float eps, int dtype, void* stream);
+/* The same for fp32 rows, with the second output in the fp16-pair layout of the two-term GEMMs (see
+ * AURORA_F32_A_SPLIT): the LayerNorm in front of a Perceiver MLP hands its result to fc1 already split.
+ * D % 32 == 0, ld_split % 32 == 0 (4-byte units). */
+int aurora_hip_layernorm_split(const float* y, int64_t ldy, const float* gain, const float* shift,
+                               const float* res, int64_t ldr, int64_t res_mod,
+                               float* out_f32, int64_t ldo, void* out_split, int64_t ld_split,
+                               int64_t M, int D, float eps, void* stream);
 
 /* ---- patch merging: 2x2 gather + LayerNorm(4D) -------------------------------------------
  * x: fp32 residual stream [B][C][H][W][D] -> out `dtype` [B][C][H2][W2][4D], H2 = ceil(H/2),

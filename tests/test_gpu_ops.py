@@ -87,6 +87,111 @@ def test_linear_fp32_by_bf16_splitting_is_fp32_grade(M, N, K):
     assert err[2] < (4e-6 if K < 64 else 2e-6) and (K < 64 or err[2] < 2 * err[0] + 1e-7), err
 
 
+@pytest.mark.parametrize("M,N,K", [(1030, 256, 96), (1279, 512, 128), (2050, 768, 160), (33000, 512, 512),
+                                   (5000, 1024, 2048)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_fp32_two_fp16_terms_full_epilogue(M, N, K, act):
+    """The ping-pong two-term kernel (128 x 256 tiles, K-stages of 32; K = 96 is its three-stage minimum) with everything
+    the epilogue can do: bias, activation, residual, second bf16 output, ragged last m-tile, padded leading dimension."""
+    L = lib()
+    a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = a @ w.T + b
+    ref = F.gelu(ref) if act == 1 else (F.silu(ref) if act == 2 else ref)
+    ref = ref + r
+    ld = N + 4
+    out = torch.full((M, ld), float("nan"), device=DEV)
+    out2 = torch.zeros((M, ld), dtype=torch.bfloat16, device=DEV)
+    with L.f32_gemm(2):
+        L.linear(a.float().to(DEV), w.float().to(DEV), b.float().to(DEV), out, out2=out2,
+                 residual=r.float().to(DEV), act=act, n=N)
+    torch.cuda.synchronize()
+    assert relerr(out[:, :N], ref) < 2e-6
+    assert relerr(out2[:, :N].float(), ref) < 5e-3
+    assert torch.isnan(out[:, N:]).all()
+
+
+def _unsplit(t):
+    """fp16-pair layout -> (high halves, remainders) as fp32 tensors of the logical shape."""
+    M, K = t.shape
+    h16 = t.contiguous().view(torch.float16).view(M, K // 32, 2, 32)
+    return h16[:, :, 0].reshape(M, K).float(), h16[:, :, 1].reshape(M, K).float()
+
+
+def test_split_f16_layout_and_values():
+    L = lib()
+    x = (rnd(70, 96, seed=5) * 3).float().to(DEV)
+    hi, lo = _unsplit(L.split_f16(x))
+    ref_hi = x.half().float()
+    assert torch.equal(hi, ref_hi) and torch.equal(lo, (x - ref_hi).half().float())
+    hi, lo = _unsplit(L.split_f16(x, scale=64.0))
+    assert torch.equal(hi, (x * 64).half().float()) and torch.equal(lo, (x * 64 - hi).half().float())
+    with pytest.raises(ValueError):
+        L.split_f16(x[:, :48].contiguous())   # K % 32 != 0
+
+
+@pytest.mark.parametrize("M,N,K", [(1030, 256, 96), (2050, 768, 160), (5000, 1024, 2048)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear_fp32_presplit_operands_are_bit_identical(M, N, K, act):
+    """A split is the same arithmetic wherever it happens: weights split at pack time, activations split by their
+    producer and results written in the pair layout must reproduce the in-kernel split bit for bit."""
+    L = lib()
+    a = rnd(M, K, seed=1).float().to(DEV)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).float().to(DEV)
+    b, r = rnd(N, seed=3).float().to(DEV), rnd(M, N, seed=4).float().to(DEV)
+    base = torch.empty((M, N), device=DEV)
+    with L.f32_gemm(2):
+        L.linear(a, w, b, base, residual=r, act=act)
+    ws, a_s = L.split_f16(w, scale=64.0), L.split_f16(a)
+    for flags, a_in in ((L.F32_W_SPLIT, a), (L.F32_W_SPLIT | L.F32_A_SPLIT, a_s)):
+        out = torch.full((M, N), float("nan"), device=DEV)
+        L.linear(a_in, ws, b, out, residual=r, act=act, presplit=flags)
+        assert torch.equal(out, base), flags
+    out = torch.zeros((M, N), device=DEV)
+    L.linear(a_s, ws, b, out, residual=r, act=act, presplit=L.F32_W_SPLIT | L.F32_A_SPLIT | L.F32_C_SPLIT)
+    torch.cuda.synchronize()
+    assert torch.equal(out, L.split_f16(base))
+    # contract violations are refused, not mis-executed
+    with pytest.raises(ValueError):
+        L.linear(a_s, w, b, out, presplit=L.F32_A_SPLIT)             # pre-split activations need pre-split weights
+    with pytest.raises(ValueError):
+        with L.bounded_activations(guard=(L.absmax(a), 100.0)):
+            L.linear(a_s, ws, b, out, presplit=L.F32_W_SPLIT | L.F32_A_SPLIT)   # ... and take no guard
+
+
+@pytest.mark.parametrize("amax", [3.0, 1.0e6])
+def test_linear_fp32_presplit_weights_guarded_pair(amax):
+    """Pre-split weights with a guard: the two-term launch runs iff the guard holds, a mode-1 launch with the same guard
+    iff it does not -- together they are the guarded mode-2 call."""
+    L = lib()
+    M, N, K = 2050, 512, 256
+    a = (rnd(M, K, seed=21) * amax).float().to(DEV)
+    w = rnd(N, K, seed=22, scale=K ** -0.5).float().to(DEV)
+    ws = L.split_f16(w, scale=64.0)
+    g = L.absmax(a)
+    base = torch.empty((M, N), device=DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    with L.bounded_activations(guard=(g, 16384.0)):
+        L.linear(a, w, None, base)
+        L.linear(a, ws, None, out, presplit=L.F32_W_SPLIT)
+    with L.f32_gemm(1, guard=(g, 16384.0)):
+        L.linear(a, w, None, out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.equal(out, base)
+
+
+def test_layernorm_split_output():
+    L = lib()
+    M, D = 1000, 1024
+    y, res = rnd(M, D, seed=1).float().to(DEV) * 3, rnd(M, D, seed=2).float().to(DEV)
+    gw, gb = rnd(D, seed=3).float().to(DEV), rnd(D, seed=4).float().to(DEV)
+    plain, both = torch.empty_like(y), torch.empty_like(y)
+    sp = torch.empty_like(y)
+    L.layernorm(y, gw, gb, res=res, out_f32=plain)
+    L.layernorm(y, gw, gb, res=res, out_f32=both, out_t=sp, split_t=True)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, both) and torch.equal(sp, L.split_f16(plain))
+
+
 @pytest.mark.parametrize("amax", [3.0, 1.0e6])
 def test_linear_fp32_range_guard_picks_the_split_on_the_device(amax):
     """With a guard, mode 2 launches both operand splits and the device word decides: activations inside fp16's range

@@ -23,13 +23,20 @@ SHAPES = [  # (name, M, N, K, weight in the step)
     ("r8.s1.qkv", 8100, 3072, 1024, 0), ("r8.s1.proj", 8100, 1024, 1024, 0), ("r8.s1.fc1", 8100, 4096, 1024, 0),
     ("r8.s1.fc2", 8100, 1024, 4096, 0), ("r8.s2.qkv", 2160, 6144, 2048, 0), ("r8.s2.proj", 2160, 2048, 2048, 0),
     ("r8.s2.fc1", 2160, 8192, 2048, 0), ("r8.s2.fc2", 2160, 2048, 8192, 0),
-    # fp32 encoder / decoder linears (run with `f32`): level aggregation and level decoder
-    ("e.kv", 907200, 1024, 512, 0), ("d.proj", 842400, 512, 512, 0), ("d.fc1", 842400, 2048, 512, 0),
-    ("d.fc2", 842400, 512, 2048, 0), ("d.kv", 194400, 1024, 1024, 0), ("e.embed", 842400, 512, 160, 0),
+    # fp32 encoder / decoder linears of the 0.25-degree step (run with `f32`): level aggregation (D = 512, 194,400 latent
+    # rows, 842,400 context rows) and level decoder (D = 1024, 842,400 query rows, 194,400 context rows)
+    ("d.fc1", 842400, 2048, 1024, 0), ("d.fc2", 842400, 1024, 2048, 0), ("d.out", 842400, 1024, 1024, 0),
+    ("d.kv", 194400, 2048, 1024, 0), ("e.kv", 842400, 1024, 512, 0), ("e.fc1", 194400, 2048, 512, 0),
+    ("e.fc2", 194400, 512, 2048, 0), ("e.embed", 842400, 512, 160, 0),
 ]
+F32_SHAPES = "d.fc1,d.fc2,d.out,d.kv,e.kv,e.fc1,e.fc2"
+# GEMM_BENCH_PRESPLIT = w | aw | awc: operands (and the result) in the fp16-pair layout of the two-term kernel
 dtype = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
 if len(sys.argv) > 2:  # restrict to the named shapes
-    SHAPES = [s_ for s_ in SHAPES if s_[0] in sys.argv[2].split(",")]
+    names = (F32_SHAPES if sys.argv[2] == "f32shapes" else sys.argv[2]).split(",")
+    SHAPES = [s_ for s_ in SHAPES if s_[0] in names]
+PRE = os.environ.get("GEMM_BENCH_PRESPLIT", "")
+FLAGS = (lib.F32_W_SPLIT if "w" in PRE else 0) | (lib.F32_A_SPLIT if "a" in PRE else 0) | (lib.F32_C_SPLIT if "c" in PRE else 0)
 ACT = int(os.environ.get("GEMM_BENCH_ACT", "0"))   # 1 = GELU epilogue
 tot_ms = tot_fl = 0.0
 for name, M, N, K, wt in SHAPES:
@@ -41,14 +48,18 @@ for name, M, N, K, wt in SHAPES:
         w.zero_()
     b = torch.rand(N, device="cuda")
     out = torch.empty(M, N, device="cuda", dtype=dtype)
+    if FLAGS & lib.F32_W_SPLIT:
+        w = lib.split_f16(w, scale=64.0)
+    if FLAGS & lib.F32_A_SPLIT:
+        a = lib.split_f16(a)
     for _ in range(2):
-        lib.linear(a, w, b, out, act=ACT)
+        lib.linear(a, w, b, out, act=ACT, presplit=FLAGS)
     torch.cuda.synchronize()
     reps = 5
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        lib.linear(a, w, b, out, act=ACT)
+        lib.linear(a, w, b, out, act=ACT, presplit=FLAGS)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
