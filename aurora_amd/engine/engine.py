@@ -248,6 +248,11 @@ class Engine:
             w_max = max(float(d[k].abs().max().item()) for k in ("to_kv", "to_out", "fc1_w", "fc2_w"))
             ln_bound = float(d["ln1_w"].abs().max().item()) * d["ln1_w"].numel() ** 0.5 + float(d["ln1_b"].abs().max().item())
             d["f16_ok"] = w_max < 1000.0 and ln_bound < _F16_SAFE
+            if d["f16_ok"]:
+                # the same weights in the fp16-pair layout (scaled by 2^6): two-term GEMMs spend no VALU work on them
+                for k in ("to_kv", "to_out", "fc1_w", "fc2_w"):
+                    if lib.presplit_ok(*d[k].shape):
+                        d[k + ".s"] = lib.split_f16(d[k], scale=64.0)
             layers.append(d)
         return layers
 
@@ -840,8 +845,21 @@ class Engine:
         for i, ly in enumerate(layers):
             inner, hd = ly["inner"], ly["head_dim"]
             bounded = lib.bounded_activations if ly["f16_ok"] else (lambda guard=None: contextlib.nullcontext())
-            with bounded(guard=(ctx_max, _F16_SAFE)):
-                kv = self._linear_new(ctx, ly["to_kv"], None, 2 * inner)
+            pre = ly["f16_ok"] and lib.two_term_free()
+
+            def guarded(a, name, n_out, limit):
+                """Guarded linear.  With pre-split weights: the two-term launch runs iff the guard holds, the three-term
+                one on the fp32 weights iff it does not (include/aurora_hip.h) -- the same result as the guarded call."""
+                if pre and name + ".s" in ly:
+                    out = self.empty(a.shape[0], n_out)
+                    with lib.f32_gemm(2, guard=(ctx_max, limit)):
+                        lib.linear(a, ly[name + ".s"], None, out, presplit=lib.F32_W_SPLIT)
+                    with lib.f32_gemm(1, guard=(ctx_max, limit)):
+                        return lib.linear(a, ly[name], None, out)
+                with bounded(guard=(ctx_max, limit)):
+                    return self._linear_new(a, ly[name], None, n_out)
+
+            kv = guarded(ctx, "to_kv", 2 * inner, _F16_SAFE)
             if "ln_k.w" in ly:  # LayerNorm over the K half, in place (perceiver.py:144-147)
                 lib.layernorm(kv, ly["ln_k.w"], ly["ln_k.b"], out_f32=kv, d=inner)
             if i == 0:
@@ -856,18 +874,26 @@ class Engine:
             del kv
             D = ly["to_out"].shape[0]
             # |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
-            with bounded(guard=(ctx_max, _F16_SAFE / ly["v_l1"])):
-                o = self._linear_new(att, ly["to_out"], None, D)
+            o = guarded(att, "to_out", D, _F16_SAFE / ly["v_l1"])
             del att
             lat1 = self.empty(n_rows, D)
-            if i == 0:
-                lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], res=latents0, res_mod=Lq, out_f32=lat1, eps=eps)
-            else:
-                lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], res=lat, out_f32=lat1, eps=eps)
+            # The MLP in the fp16-pair layout end to end: LayerNorm writes its result a second time already split, fc1
+            # reads that and writes its GELU'd result split, fc2 reads that -- neither GEMM splits anything.
+            pairs = pre and "fc1_w.s" in ly and "fc2_w.s" in ly and D % 32 == 0
+            lat1_s = self.empty(n_rows, D) if pairs else None
+            res_kw = dict(res=latents0, res_mod=Lq) if i == 0 else dict(res=lat)
+            lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], out_f32=lat1, eps=eps, out_t=lat1_s, split_t=pairs, **res_kw)
             del o
-            with bounded():    # fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU
-                hid = self._linear_new(lat1, ly["fc1_w"], ly["fc1_b"], ly["fc1_w"].shape[0], act=lib.ACT_GELU)
-                y = self._linear_new(hid, ly["fc2_w"], ly["fc2_b"], D)
+            if pairs:
+                both = lib.F32_A_SPLIT | lib.F32_W_SPLIT
+                hid = self.empty(n_rows, ly["fc1_w"].shape[0])
+                lib.linear(lat1_s, ly["fc1_w.s"], ly["fc1_b"], hid, act=lib.ACT_GELU, presplit=both | lib.F32_C_SPLIT)
+                y = lib.linear(hid, ly["fc2_w.s"], ly["fc2_b"], self.empty(n_rows, D), presplit=both)
+                del lat1_s
+            else:
+                with bounded():    # fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU
+                    hid = self._linear_new(lat1, ly["fc1_w"], ly["fc1_b"], ly["fc1_w"].shape[0], act=lib.ACT_GELU)
+                    y = self._linear_new(hid, ly["fc2_w"], ly["fc2_b"], D)
             del hid
             lib.layernorm(y, ly["ln2_w"], ly["ln2_b"], res=lat1, out_f32=y, eps=eps)
             lat = y

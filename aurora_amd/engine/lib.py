@@ -263,6 +263,17 @@ class bounded_activations(f32_gemm):
 F32_A_SPLIT, F32_W_SPLIT, F32_C_SPLIT = 4, 8, 16   # include/aurora_hip.h: operands / output in the fp16-pair layout
 
 
+def two_term_free() -> bool:
+    """True unless the user pinned an fp32 GEMM mode (AURORA_F32_GEMM or an enclosing `f32_gemm`) -- the condition under
+    which `bounded_activations` switches to the two-term split, and so the one for handing it pre-split operands."""
+    return _f32_state()[0] < 0 and os.environ.get("AURORA_F32_GEMM") is None and os.environ.get("AURORA_NO_PRESPLIT") is None
+
+
+def presplit_ok(n: int, k: int) -> bool:
+    """Shapes the pre-split form of the two-term kernel takes (include/aurora_hip.h)."""
+    return n % 256 == 0 and k % 32 == 0 and k >= 96
+
+
 def split_f16(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 rows -> the fp16-pair layout of the two-term GEMMs (same shape, dtype float32 as a container: per 32
     features 32 high halves, then 32 remainders).  Weights take scale = 64."""
