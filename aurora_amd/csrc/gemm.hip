@@ -117,6 +117,7 @@ __device__ __forceinline__ void store16<bf16_t>(bf16_t* dst, const float (&v)[16
   }
 }
 
+template <uint32_t GN = 8>
 __device__ __forceinline__ void tile_of_block(uint32_t bid, uint32_t nb, uint32_t tiles_m, uint32_t tiles_n,
                                               uint32_t& tile_m, uint32_t& tile_n);
 
@@ -305,12 +306,14 @@ __device__ __forceinline__ int swz2_w(int row) { return swz2((row >> 4) & 3); }
 // logical ids; inside it n-tiles are visited in groups of `GN` with the m-tile index in between,
 // so the workgroups that run together on one XCD share a few activation tiles AND a few weight
 // tiles (both then come out of that XCD's 4 MiB L2).
+// (GN = 8 for the 256 x 256 bf16 tiles; the fp32 ping-pong kernel's 128 x 256 tiles stage twice the weight bytes per
+// activation byte and do best with 16 m-tiles x 2 n-tiles per XCD -- in-step A/B over GN = 2 .. 32, profiles/r02_ab_tile_group.log)
+template <uint32_t GN>
 __device__ __forceinline__ void tile_of_block(uint32_t bid, uint32_t nb, uint32_t tiles_m, uint32_t tiles_n,
                                               uint32_t& tile_m, uint32_t& tile_n) {
   const uint32_t q8 = nb >> 3, r8 = nb & 7;
   const uint32_t xcd = bid & 7, idx = bid >> 3;
   const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  constexpr uint32_t GN = 8;
   const uint32_t full = (tiles_n / GN) * GN;          // n-tiles covered by complete groups
   const uint32_t per_group = GN * tiles_m;
   if (logical < (full / GN) * per_group) {
@@ -1305,7 +1308,7 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
   const int wm = wave >> 2, wn = wave & 3;   // waves w and w+4 share a SIMD; wm = 1 runs one phase behind
 
   uint32_t tile_m, tile_n;
-  tile_of_block(blockIdx.x, (uint32_t)p.n_blocks, (uint32_t)(p.n_blocks / p.tiles_n), (uint32_t)p.tiles_n, tile_m, tile_n);
+  tile_of_block<2>(blockIdx.x, (uint32_t)p.n_blocks, (uint32_t)(p.n_blocks / p.tiles_n), (uint32_t)p.tiles_n, tile_m, tile_n);
   const int64_t m0 = (int64_t)tile_m * VM;
   const int n0 = (int)tile_n * VN;
 
@@ -1663,11 +1666,15 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
     else if (dtype == AURORA_F32)
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else {
-      static const int variant = [] { const char* e = getenv("AURORA_GEMM_VARIANT"); return e ? atoi(e) : 8; }();
+      static const int variant = [] { const char* e = getenv("AURORA_GEMM_VARIANT"); return e ? atoi(e) : 5; }();
       // AURORA_GEMM_VARIANT (A/B switch, profiles/r02_ab_gemm_variants.log):
-      //   8 (default) ping-pong main loop; persistent form of it where that wins (N >= 1024 and K <= 2048: +3..8 %;
-      //     the long-K / two-n-tile shapes spend little of a tile outside the main loop and lose 1-2 % to it)
-      //   7 ping-pong, persistent wherever legal      5 ping-pong, never persistent
+      //   5 (default) ping-pong main loop, one workgroup per tile
+      //   8 ping-pong; persistent form of it where that wins IN ISOLATION (N >= 1024 and K <= 2048: +3..8 % when one launch
+      //     is repeated on cache-resident operands; the long-K / two-n-tile shapes lose 1-2 % to it).  Inside the forecast
+      //     step the persistent form is 0.4 ms per step SLOWER than 5 (profiles/r02_ab_variants_instep.log: 74.94 vs 74.58 ms
+      //     of bf16 GEMM, twice): its static tile-to-CU assignment cannot absorb the uneven tile times of cold operands,
+      //     which the hardware dispatcher does for free -- so it is not the default
+      //   7 ping-pong, persistent wherever legal
       //   4 in-phase ring kernel + static wave priority, persistent by the same shape rule (round 2's first default)
       //   3 / 2 in-phase, persistent wherever legal, with / without priority      1 / 0 in-phase ring kernel with / without
       const bool plain = C2 == nullptr && residual == nullptr && vec && N % BN2 == 0 && p.k_tiles >= 8;
