@@ -550,17 +550,18 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     float* o = (float*)m.arena.take((size_t)n_rows * Dd * 4);
     // |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
     guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, F16_SAFE / ly.v_l1);
-    float* lat1 = (float*)m.arena.take((size_t)n_rows * Dd * 4);
-    // The MLP in the fp16-pair layout end to end: the LayerNorm writes its result a second time already split, fc1 reads
-    // that and writes its GELU'd result split (nothing else reads it), fc2 reads that -- neither GEMM splits anything.
+    // The MLP in the fp16-pair layout end to end: the LayerNorm writes its result already split (and ONLY split), fc1
+    // reads that and writes its GELU'd result split, fc2 reads that -- neither GEMM splits anything -- and the LayerNorm
+    // behind the MLP takes the split array as its residual.
     const bool pairs = ly.fc1_s && ly.fc2_s && Dd % 32 == 0;
-    float* lat1_s = pairs ? (float*)m.arena.take((size_t)n_rows * Dd * 4) : nullptr;
+    float* lat1 = (float*)m.arena.take((size_t)n_rows * Dd * 4);   // fp32 values, or their fp16 pairs
     {
       const float* res_ = i == 0 ? latents0 : lat;
       const int64_t mod_ = i == 0 ? Lq : 0;
       if (pairs)
         timed(m, L.stream, K_LAYERNORM, 0.0, [&] {
-          return aurora_hip_layernorm_split(o, Dd, ly.ln1_w, ly.ln1_b, res_, Dd, mod_, lat1, Dd, lat1_s, Dd, n_rows, Dd, eps, L.stream);
+          return aurora_hip_layernorm_split(o, Dd, ly.ln1_w, ly.ln1_b, res_, Dd, mod_, 0, nullptr, 0, lat1, Dd, n_rows, Dd, eps,
+                                            L.stream);
         });
       else L.layernorm(o, Dd, ly.ln1_w, ly.ln1_b, res_, Dd, mod_, lat1, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
     }
@@ -568,7 +569,7 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     // fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU: bounded whatever the inputs are
     if (pairs) {
       const int all = 2 | AURORA_F32_A_SPLIT | AURORA_F32_W_SPLIT;
-      L.linear(lat1_s, Dd, ly.fc1_s, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
+      L.linear(lat1, Dd, ly.fc1_s, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
                nullptr, 0, all | AURORA_F32_C_SPLIT);
       L.linear(hid, ly.hidden, ly.fc2_s, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0, all);
     } else {
@@ -577,7 +578,11 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
       L.linear(hid, ly.hidden, ly.fc2_w, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0,
                ly.f16_mode);
     }
-    L.layernorm(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, y, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
+    if (pairs)
+      timed(m, L.stream, K_LAYERNORM, 0.0, [&] {
+        return aurora_hip_layernorm_split(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, 1, y, Dd, nullptr, 0, n_rows, Dd, eps, L.stream);
+      });
+    else L.layernorm(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, y, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
     m.arena.top = after_y;            // temporaries of this layer are dead (a previous layer's result stays below y)
     lat = y;
     if (i == 0) out_mark = mark0;

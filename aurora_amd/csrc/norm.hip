@@ -43,6 +43,7 @@ struct LnArgs {
   float* out_f32; int64_t ldo; void* out_t; int64_t ldt;
   int64_t M; int D; float eps;
   int split_t;   // fp32 kernel: out_t receives the fp16-pair layout of the two-term GEMMs (aurora_hip_layernorm_split)
+  int split_res; // fp32 kernel: the residual rows are in that layout (value = high half + remainder)
 };
 
 template <typename T, int MAXC>
@@ -135,7 +136,18 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
         if (p.shift) t += sh[j];
         o[j] = t;
       }
-      if (rr) {
+      if (rr && p.split_res) {
+        // features e..e+3 of a pair-layout row: four fp16 high halves, their remainders 64 bytes further on
+        const char* s = reinterpret_cast<const char*>(rr) + (e & ~31) * 4 + (e & 31) * 2;
+        const u32x2 h = *reinterpret_cast<const u32x2*>(s);
+        const u32x2 l = *reinterpret_cast<const u32x2*>(s + 64);
+        // (halves are taken out of the words by hand: bit-casting the ELEMENTS of the loaded vector to fp16 pairs made hipcc
+        // read the first word twice)
+        auto half = [](uint32_t w, int hi) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(hi ? w >> 16 : w & 0xffffu)); };
+        const uint32_t hw[2] = {h.x, h.y}, lw[2] = {l.x, l.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += half(hw[j >> 1], j & 1) + half(lw[j >> 1], j & 1);
+      } else if (rr) {
         float r4[4];
         load4(rr + e, r4);
 #pragma unroll
@@ -261,28 +273,31 @@ using namespace aurora;
 
 static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const float* shift, const float* res, int64_t ldr,
                           int64_t res_mod, float* out_f32, int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D,
-                          float eps, int dtype, int split_t, void* stream);
+                          float eps, int dtype, int split_t, int split_res, void* stream);
 
 extern "C" int aurora_hip_layernorm(const void* y, int64_t ldy, const float* gain, const float* shift,
                                     const float* res, int64_t ldr, int64_t res_mod, float* out_f32,
                                     int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D, float eps,
                                     int dtype, void* stream) {
-  return layernorm_impl(y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps, dtype, 0, stream);
+  return layernorm_impl(y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps, dtype, 0, 0, stream);
 }
 
 extern "C" int aurora_hip_layernorm_split(const float* y, int64_t ldy, const float* gain, const float* shift,
-                                          const float* res, int64_t ldr, int64_t res_mod, float* out_f32,
+                                          const void* res, int64_t ldr, int64_t res_mod, int res_is_split, float* out_f32,
                                           int64_t ldo, void* out_split, int64_t ld_split, int64_t M, int D, float eps,
                                           void* stream) {
-  AURORA_CHECK_ARG(out_split != nullptr && D % 32 == 0 && ld_split % 32 == 0 && ld_split >= D,
-                   "layernorm_split: D=%d and the pair-layout stride must be multiples of 32", D);
-  return layernorm_impl(y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_split, ld_split, M, D, eps, AURORA_F32, 1,
-                        stream);
+  AURORA_CHECK_ARG(D % 32 == 0, "layernorm_split: D=%d must be a multiple of 32", D);
+  AURORA_CHECK_ARG(out_split == nullptr || (ld_split % 32 == 0 && ld_split >= D),
+                   "layernorm_split: the pair-layout output stride must be a multiple of 32, >= D");
+  AURORA_CHECK_ARG(!res_is_split || (res != nullptr && ldr % 32 == 0 && ldr >= D),
+                   "layernorm_split: the pair-layout residual stride must be a multiple of 32, >= D");
+  return layernorm_impl(y, ldy, gain, shift, static_cast<const float*>(res), ldr, res_mod, out_f32, ldo, out_split, ld_split,
+                        M, D, eps, AURORA_F32, out_split ? 1 : 0, res_is_split ? 1 : 0, stream);
 }
 
 static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const float* shift, const float* res, int64_t ldr,
                           int64_t res_mod, float* out_f32, int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D,
-                          float eps, int dtype, int split_t, void* stream) {
+                          float eps, int dtype, int split_t, int split_res, void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "layernorm: bad dtype");
   AURORA_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 4096, "layernorm: D=%d must be a multiple of 8, <= 4096", D);
   const int es = dtype == AURORA_F32 ? 4 : 2;
@@ -293,7 +308,7 @@ static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const f
                    "layernorm: unaligned residual/output rows");
   AURORA_CHECK_ARG(out_f32 || out_t, "layernorm: no output");
   if (M <= 0) return AURORA_OK;
-  LnArgs p{y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps, split_t};
+  LnArgs p{y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps, split_t, split_res};
   if (dtype == AURORA_F32) {
     const dim3 grid(row_blocks(M)), block(256);
     if (D <= 256) hipLaunchKernelGGL(layernorm_f32_kernel<1>, grid, block, 0, as_stream(stream), p);

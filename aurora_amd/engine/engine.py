@@ -876,26 +876,28 @@ class Engine:
             # |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
             o = guarded(att, "to_out", D, _F16_SAFE / ly["v_l1"])
             del att
-            lat1 = self.empty(n_rows, D)
-            # The MLP in the fp16-pair layout end to end: LayerNorm writes its result a second time already split, fc1
-            # reads that and writes its GELU'd result split, fc2 reads that -- neither GEMM splits anything.
+            lat1 = self.empty(n_rows, D)   # fp32 values, or their fp16 pairs
+            # The MLP in the fp16-pair layout end to end: LayerNorm writes its result already split (and only split),
+            # fc1 reads that and writes its GELU'd result split, fc2 reads that -- neither GEMM splits anything -- and
+            # the LayerNorm behind the MLP takes the split array as its residual.
             pairs = pre and "fc1_w.s" in ly and "fc2_w.s" in ly and D % 32 == 0
-            lat1_s = self.empty(n_rows, D) if pairs else None
             res_kw = dict(res=latents0, res_mod=Lq) if i == 0 else dict(res=lat)
-            lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], out_f32=lat1, eps=eps, out_t=lat1_s, split_t=pairs, **res_kw)
+            if pairs:
+                lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], eps=eps, out_t=lat1, split_t=True, **res_kw)
+            else:
+                lib.layernorm(o, ly["ln1_w"], ly["ln1_b"], out_f32=lat1, eps=eps, **res_kw)
             del o
             if pairs:
                 both = lib.F32_A_SPLIT | lib.F32_W_SPLIT
                 hid = self.empty(n_rows, ly["fc1_w"].shape[0])
-                lib.linear(lat1_s, ly["fc1_w.s"], ly["fc1_b"], hid, act=lib.ACT_GELU, presplit=both | lib.F32_C_SPLIT)
+                lib.linear(lat1, ly["fc1_w.s"], ly["fc1_b"], hid, act=lib.ACT_GELU, presplit=both | lib.F32_C_SPLIT)
                 y = lib.linear(hid, ly["fc2_w.s"], ly["fc2_b"], self.empty(n_rows, D), presplit=both)
-                del lat1_s
             else:
                 with bounded():    # fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU
                     hid = self._linear_new(lat1, ly["fc1_w"], ly["fc1_b"], ly["fc1_w"].shape[0], act=lib.ACT_GELU)
                     y = self._linear_new(hid, ly["fc2_w"], ly["fc2_b"], D)
             del hid
-            lib.layernorm(y, ly["ln2_w"], ly["ln2_b"], res=lat1, out_f32=y, eps=eps)
+            lib.layernorm(y, ly["ln2_w"], ly["ln2_b"], res=lat1, out_f32=y, eps=eps, split_res=pairs)
             lat = y
         return lat
 

@@ -56,7 +56,7 @@ _SIGNATURES = {
                                      c_int, c_int, c_void_p, c_float, c_void_p]),
     "aurora_hip_absmax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "aurora_hip_split_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
-    "aurora_hip_layernorm_split": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+    "aurora_hip_layernorm_split": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                            c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
     "aurora_hip_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                   c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
@@ -340,8 +340,9 @@ def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], out: t
 def layernorm(y: torch.Tensor, gain: Optional[torch.Tensor], shift: Optional[torch.Tensor], *,
               res: Optional[torch.Tensor] = None, res_mod: int = 0,
               out_f32: Optional[torch.Tensor] = None, out_t: Optional[torch.Tensor] = None,
-              eps: float = 1e-5, d: Optional[int] = None, split_t: bool = False) -> None:
-    """`split_t`: fp32 rows only -- `out_t` receives the fp16-pair layout (aurora_hip_layernorm_split)."""
+              eps: float = 1e-5, d: Optional[int] = None, split_t: bool = False, split_res: bool = False) -> None:
+    """`split_t` / `split_res` (fp32 rows only, aurora_hip_layernorm_split): `out_t` receives the fp16-pair layout /
+    `res` is in it."""
     ldy, dy = _rows(y)
     D = d if d is not None else dy
     M = y.shape[0]
@@ -359,11 +360,12 @@ def layernorm(y: torch.Tensor, gain: Optional[torch.Tensor], shift: Optional[tor
         ldt, _ = _rows(out_t)
     nbytes = M * D * (y.element_size() + (4 if res is not None else 0) + (4 if out_f32 is not None else 0)
                       + (y.element_size() if out_t is not None else 0))
-    if split_t:
-        assert y.dtype == torch.float32 and out_t is not None
+    if split_t or split_res:
+        assert y.dtype == torch.float32 and (out_t is not None) == split_t and (res is not None or not split_res)
         with _Timed("layernorm", float(nbytes)):
             _check(load().aurora_hip_layernorm_split(_ptr(y), ldy, _ptr(gain), _ptr(shift), _ptr(res), ldr, res_mod,
-                                                     _ptr(out_f32), ldo, _ptr(out_t), ldt, M, D, eps, _stream()))
+                                                     1 if split_res else 0, _ptr(out_f32), ldo, _ptr(out_t), ldt, M, D,
+                                                     eps, _stream()))
         return
     with _Timed("layernorm", float(nbytes)):
         _check(load().aurora_hip_layernorm(_ptr(y), ldy, _ptr(gain), _ptr(shift), _ptr(res), ldr, res_mod,

@@ -131,11 +131,13 @@ int aurora_hip_layernorm(const void* y, int64_t ldy, const float* gain, const fl
                          const float* res, int64_t ldr, int64_t res_mod,
                          float* out_f32, int64_t ldo, void* out_t, int64_t ldt,
                          int64_t M, int D, float eps, int dtype, void* stream);
-/* The same for fp32 rows, with the second output in the fp16-pair layout of the two-term GEMMs (see
- * AURORA_F32_A_SPLIT): the LayerNorm in front of a Perceiver MLP hands its result to fc1 already split.
- * D % 32 == 0, ld_split % 32 == 0 (4-byte units). */
+/* The same for fp32 rows, with the fp16-pair layout of the two-term GEMMs (see AURORA_F32_A_SPLIT) on either side: the
+ * LayerNorm in front of a Perceiver MLP hands its result to fc1 already split (out_split; out_f32 may then be NULL),
+ * and the LayerNorm behind the MLP takes that same array as its residual (res_is_split = 1: the residual value is
+ * high half + remainder, equal to the fp32 value to 2^-23 relative) -- the fp32 copy is never written.
+ * D % 32 == 0; pair-layout strides % 32 == 0 (4-byte units).  Either output may be NULL, not both. */
 int aurora_hip_layernorm_split(const float* y, int64_t ldy, const float* gain, const float* shift,
-                               const float* res, int64_t ldr, int64_t res_mod,
+                               const void* res, int64_t ldr, int64_t res_mod, int res_is_split,
                                float* out_f32, int64_t ldo, void* out_split, int64_t ld_split,
                                int64_t M, int D, float eps, void* stream);
 

@@ -190,6 +190,18 @@ def test_layernorm_split_output():
     L.layernorm(y, gw, gb, res=res, out_f32=both, out_t=sp, split_t=True)
     torch.cuda.synchronize()
     assert torch.equal(plain, both) and torch.equal(sp, L.split_f16(plain))
+    only = torch.empty_like(y)
+    L.layernorm(y, gw, gb, res=res, out_t=only, split_t=True)          # the fp32 copy is optional
+    assert torch.equal(only, sp)
+    # a residual in the pair layout is worth high half + remainder: the fp32 value to 2^-23 relative
+    from_pairs = torch.empty_like(y)
+    L.layernorm(y, gw, gb, res=L.split_f16(res), out_f32=from_pairs, split_res=True)
+    hi, lo = _unsplit(L.split_f16(res))
+    exact = torch.empty_like(y)
+    L.layernorm(y, gw, gb, res=hi + lo, out_f32=exact)
+    torch.cuda.synchronize()
+    assert torch.equal(from_pairs, exact)
+    assert (from_pairs - plain).abs().max().item() <= 2e-6   # |res| <= 4.5: 2^-23 of it, plus one rounding of the sum
 
 
 @pytest.mark.parametrize("amax", [3.0, 1.0e6])
