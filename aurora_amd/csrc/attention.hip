@@ -78,7 +78,7 @@ __device__ __forceinline__ u32x4 pair_rows(u32x2 a, u32x2 b) {
 
 // FULL: the window has exactly 144 tokens (every stage of the published 0.25 / 0.1 / 0.4 degree
 // configurations): tile counts become compile-time constants.
-template <bool FULL, bool WIDE>
+template <bool FULL, int WIDE>   // WIDE: 0 8-byte result stores, 1 16-byte, 2 16-byte covering whole 128-byte rows
 __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * MAXN * 128 + MAXN * 4 + MAXN + 16];
   char* const s_k = smem;                 // [144][128 B], 16-byte pieces XOR-swizzled by row & 7
@@ -261,7 +261,26 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
       return u32x2{pack_bf16x2(o.x * inv, o.y * inv), pack_bf16x2(o.z * inv, o.w * inv)};
     };
     const bool live = tq >= 0 && tq < p.L_out;
-    if constexpr (WIDE) {
+    if constexpr (WIDE == 2) {
+      // As WIDE == 1 below, then queries i and i ^ 8 trade one 16-byte piece each (a DPP rotation of the 16-lane row by
+      // 8), so that a store instruction writes the WHOLE 128-byte row of eight queries instead of half a row of
+      // sixteen: the first covers queries 0-7 of the tile (lanes i16 < 8 their own first half, lanes i16 >= 8 the second
+      // half of query i16 - 8), the second queries 8-15.  No cache line is written in two halves.
+      const bool odd = (g & 1) != 0, upper = i16 >= 8;
+      const u32x4 v0 = pair_rows(pv(0), pv(1)), v1 = pair_rows(pv(2), pv(3));
+      const u32x4 give = upper ? v0 : v1;   // what the partner lane stores for me
+      auto ror8 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true); };   // row_ror:8
+      const u32x4 got = u32x4{ror8(give.x), ror8(give.y), ror8(give.z), ror8(give.w)};
+      const int tq_p = (int)ror8((uint32_t)tq);
+      const bool live_p = tq_p >= 0 && tq_p < p.L_out;
+      const int piece = odd ? 16 + 4 * (g - 1) : 4 * g;
+      // first instruction: rows of queries 0-7; second: rows of queries 8-15
+      const int64_t t_a = upper ? tq_p : tq, t_b = upper ? tq : tq_p;
+      const bool l_a = upper ? live_p : live, l_b = upper ? live : live_p;
+      const int col_a = col_q + (upper ? 32 : 0) + piece, col_b = col_a;
+      if (l_a) *reinterpret_cast<u32x4*>(out + t_a * p.D + col_a) = upper ? got : v0;
+      if (l_b) *reinterpret_cast<u32x4*>(out + t_b * p.D + col_b) = upper ? v1 : got;
+    } else if constexpr (WIDE == 1) {
       // The C fragment gives a lane 4 consecutive d (8 bytes) per d-tile.  Lanes g, g^1 trade halves of two d-tiles so
       // that every lane stores 16 bytes and four lanes cover 64 contiguous bytes of the output row.
       const bool odd = (g & 1) != 0;
@@ -651,14 +670,16 @@ extern "C" int aurora_hip_window_attention(const void* qkv, const float* qkv_bia
   AURORA_CHECK_ARG(blocks < ((int64_t)1 << 31), "window_attention: grid too large");
   AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens, L_out};
   if (dtype == AURORA_BF16) {
-    static const int variant = [] { const char* e = getenv("AURORA_ATTN_VARIANT"); return e ? atoi(e) : 3; }();
-    if (variant == 0 || variant == 3) {   // one workgroup per (window, head); 3: 16-byte result stores
+    static const int variant = [] { const char* e = getenv("AURORA_ATTN_VARIANT"); return e ? atoi(e) : 4; }();
+    if (variant == 0 || variant == 3 || variant == 4) {   // one workgroup per (window, head); 3: 16-byte result stores; 4: whole rows
       if (win_tokens != MAXN)
-        hipLaunchKernelGGL((window_attention_bf16<false, true>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+        hipLaunchKernelGGL((window_attention_bf16<false, 1>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
       else if (variant == 0)
-        hipLaunchKernelGGL((window_attention_bf16<true, false>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+        hipLaunchKernelGGL((window_attention_bf16<true, 0>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+      else if (variant == 3)
+        hipLaunchKernelGGL((window_attention_bf16<true, 1>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
       else
-        hipLaunchKernelGGL((window_attention_bf16<true, true>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+        hipLaunchKernelGGL((window_attention_bf16<true, 2>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
     } else {
       // persistent: 4 workgroups per CU (LDS-limited), grid-stride over the (batch, window, head) items
       const int64_t resident = (int64_t)device_cus() * 4;

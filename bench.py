@@ -260,7 +260,7 @@ def main() -> None:
                                        "replicas": f"replica x{world} (independent forecasts, no data-path "
                                                    "collective)"}[mode]},
             "roofline": {
-                "kernel": "linear_kernel_256pp / linear_kernel_256p<0,1> (bf16 MFMA GEMM, ping-pong LDS ring; all backbone linears)", "bound": "mfma",
+                "kernel": "linear_kernel_256pp (bf16 MFMA GEMM, ping-pong LDS ring; all backbone linears)", "bound": "mfma",
                 "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_source": f"profiles/{pmc[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command; "
