@@ -1422,6 +1422,66 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
 #pragma unroll
   for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
   const bool vec = p.vec_store != 0;
+  if (vec && p.C2 == nullptr && p.res == nullptr) {   // (uniform)
+    // Plain result (fp32 or fp16 pairs): through LDS, so that a store instruction writes four whole 256-byte row
+    // segments with consecutive lanes on consecutive 16-byte pieces.  The direct form below has lane (i16, g) write 16
+    // bytes of row i16 at a 64-byte stride -- every instruction touches 32 cache lines, 32 bytes each, and the CU's
+    // store path takes as long over a tile's 128 KiB as 6-8 K-stages of MFMAs.  The ring is dead after the main loop;
+    // each wave takes 16 KiB of it for its 64 x 64 results, stored as the exact bytes of the output rows (the pair
+    // layout keeps a wave's 64 features in 256 contiguous bytes too: two groups of 32 high halves + 32 remainders),
+    // 16-byte pieces XOR-swizzled by row & 7.
+    // (both halves are past their last LDS read: the barrier above is the late half's last in-loop one)
+    char* mine = smem + wave * 16384;
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+      float v[16];
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) {
+        v[4 * fn + 0] = fmaf(acc[fn][fm].x, 0.015625f, bias_v[4 * fn + 0]);
+        v[4 * fn + 1] = fmaf(acc[fn][fm].y, 0.015625f, bias_v[4 * fn + 1]);
+        v[4 * fn + 2] = fmaf(acc[fn][fm].z, 0.015625f, bias_v[4 * fn + 2]);
+        v[4 * fn + 3] = fmaf(acc[fn][fm].w, 0.015625f, bias_v[4 * fn + 3]);
+      }
+      if (p.act == AURORA_ACT_GELU || p.act == ACT_GELU_FAST) {
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+          const f32x2_hw r = gelu_erf_fast2(f32x2_hw{v[t], v[t + 1]});
+          v[t] = r.x;
+          v[t + 1] = r.y;
+        }
+      } else if (p.act == AURORA_ACT_SILU) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
+      }
+      const int row = 16 * fm + i16, sw = row & 7;
+      char* lrow = mine + row * 256;
+      if (p.out_split) {
+        uint32_t h[8], l[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) split_pair_f16(v[2 * t], v[2 * t + 1], h[t], l[t]);
+        // features 16g..16g+15 = halves 16 (g & 1).. of group g >> 1: pieces 8 (g >> 1) + 2 (g & 1) + {0, 1}, remainders + 4
+        const int pc = 8 * (g >> 1) + 2 * (g & 1);
+        *reinterpret_cast<u32x4*>(lrow + (((pc + 0) ^ sw) << 4)) = u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(lrow + (((pc + 1) ^ sw) << 4)) = u32x4{h[4], h[5], h[6], h[7]};
+        *reinterpret_cast<u32x4*>(lrow + (((pc + 4) ^ sw) << 4)) = u32x4{l[0], l[1], l[2], l[3]};
+        *reinterpret_cast<u32x4*>(lrow + (((pc + 5) ^ sw) << 4)) = u32x4{l[4], l[5], l[6], l[7]};
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(lrow + (((4 * g + q) ^ sw) << 4)) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      }
+    }
+    const int rr = lane >> 4, cc = lane & 15;
+    float* cbase = reinterpret_cast<float*>(p.C) + n0 + wn * 64 + cc * 4;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + rr;
+      const f32x4 d = *reinterpret_cast<const f32x4*>(mine + row * 256 + ((cc ^ (row & 7)) << 4));
+      const int64_t m = m0 + wm * 64 + row;
+      if (m < p.M) *reinterpret_cast<f32x4*>(cbase + m * p.ldc) = d;
+    }
+    return;
+  }
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) {
     const int64_t m = m0 + wm * 64 + 16 * fm + i16;
