@@ -92,13 +92,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs p) {
 // instruction of a wave covers 1 KiB contiguous.  (The generic kernel above gives a lane 8 consecutive features,
 // 32 bytes for fp32, so each of its two 16-byte accesses touches every line of the row only half: measured
 // 3.0 TB/s on the 842400 x 512 decoder LayerNorms against 6.4 TB/s for the bf16-input ones.)
-template <int NC>   // chunks of 256 features
+template <typename T, int NC>   // chunks of 256 features
 __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= p.M) return;
   const int n_pieces = p.D >> 2;
-  const float* yr = reinterpret_cast<const float*>(p.y) + row * p.ldy;
+  const T* yr = reinterpret_cast<const T*>(p.y) + row * p.ldy;
   float v[NC][4];
   float s = 0.f;
 #pragma unroll
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
         *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(d + 64) = u32x2{l0, l1};
       } else if (p.out_t) {
-        store4(reinterpret_cast<float*>(p.out_t) + row * p.ldt + e, o);
+        store4(reinterpret_cast<T*>(p.out_t) + row * p.ldt + e, o);
       }
     }
   }
@@ -311,12 +311,25 @@ static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const f
   LnArgs p{y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps, split_t, split_res};
   if (dtype == AURORA_F32) {
     const dim3 grid(row_blocks(M)), block(256);
-    if (D <= 256) hipLaunchKernelGGL(layernorm_f32_kernel<1>, grid, block, 0, as_stream(stream), p);
-    else if (D <= 512) hipLaunchKernelGGL(layernorm_f32_kernel<2>, grid, block, 0, as_stream(stream), p);
-    else if (D <= 1024) hipLaunchKernelGGL(layernorm_f32_kernel<4>, grid, block, 0, as_stream(stream), p);
-    else if (D <= 2048) hipLaunchKernelGGL(layernorm_f32_kernel<8>, grid, block, 0, as_stream(stream), p);
-    else hipLaunchKernelGGL(layernorm_f32_kernel<16>, grid, block, 0, as_stream(stream), p);
+    if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<float, 1>), grid, block, 0, as_stream(stream), p);
+    else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<float, 2>), grid, block, 0, as_stream(stream), p);
+    else if (D <= 1024) hipLaunchKernelGGL((layernorm_f32_kernel<float, 4>), grid, block, 0, as_stream(stream), p);
+    else if (D <= 2048) hipLaunchKernelGGL((layernorm_f32_kernel<float, 8>), grid, block, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((layernorm_f32_kernel<float, 16>), grid, block, 0, as_stream(stream), p);
   } else {
+    // bf16 rows go through the 4-features-per-lane kernel as well: every access of a wave covers whole cache lines (8-byte
+    // bf16 pieces, 16-byte fp32 pieces on consecutive lanes), where the 8-features-per-lane kernel reads and writes the
+    // fp32 residual stream in two interleaved halves.  18.07 -> 17.43 ms of LayerNorm per step in the same run
+    // (profiles/r02_ab_ln_layout.log); AURORA_LN_VARIANT=0 selects the old kernel.
+    static const int variant = [] { const char* e = getenv("AURORA_LN_VARIANT"); return e ? atoi(e) : 1; }();
+    if (variant == 1 && D % 4 == 0 && D <= 2048) {
+      const dim3 grid(row_blocks(M)), block(256);
+      if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 1>), grid, block, 0, as_stream(stream), p);
+      else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 2>), grid, block, 0, as_stream(stream), p);
+      else if (D <= 1024) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 4>), grid, block, 0, as_stream(stream), p);
+      else hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 8>), grid, block, 0, as_stream(stream), p);
+      return check_launch("layernorm");
+    }
     AURORA_DISPATCH_ROW(layernorm_kernel, bf16_t, D, dim3(row_blocks(M)), dim3(256), 0, as_stream(stream), p);
   }
   return check_launch("layernorm");
