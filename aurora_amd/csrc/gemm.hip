@@ -1557,6 +1557,231 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
   *reinterpret_cast<u32x4*>(d + 64) = u32x4{l[0], l[1], l[2], l[3]};
 }
 
+
+// =================================================================================================
+// bf16 linear + (adaptive) LayerNorm + residual in one launch, for D = 512 (stage 0 of the backbone):
+//     x_out = x_in + LN(A W^T + bias) * gain + shift,   shadow = bf16(x_out)
+// i.e. `x = shortcut + norm(proj(...), c)` / `x = x + norm(mlp(x), c)` of a Swin block (swin3d.py:507-508, film.py:38-49)
+// without the bf16 round trip of the linear's result through HBM (2 of the 14 bytes per element the linear + LayerNorm
+// pair moves) and without the second launch.  A workgroup must own whole rows: the tile is 128 x 512 -- 8 waves as
+// 2 (m) x 4 (n), wave tile 64 x 128 (128 accumulator registers, the same as the 128 x 64 tile of the square kernels),
+// K-stages of 64 bytes per row (8 KiB of activations + 32 KiB of weights), three-stage ring, ping-pong schedule.
+// Epilogue: bias, rounding to bf16 (the reference's linear yields bf16 under autocast; statistics are taken of the
+// rounded values, as the separate kernels do), two-pass fp32 row statistics (lane -> 4 lane groups by permlane swaps ->
+// 4 waves through LDS), then 16 rows at a time through LDS so that every global access of the residual stream covers
+// whole cache lines: a lane reads 4 consecutive features of a row, normalises, adds the fp32 residual, writes fp32 and
+// bf16.  D = 1024 / 2048 would need 64 / 32-row tiles (fetch-bound) or a cross-workgroup statistics exchange: not built.
+// =================================================================================================
+constexpr int FM = 128, FN = 512, FTHREADS = 512, FNST = 3;
+constexpr int FOPER_X = FM * ROW2, FOPER_W = FN * ROW2, FSTAGE = FOPER_X + FOPER_W;   // 8 + 32 = 40 KiB
+
+struct LinearLnArgs {
+  const char* A; int64_t lda_b; const char* W; int64_t ldw_b;
+  const float* bias; const float* gain; const float* shift;
+  const float* x_in; int64_t ldx; float* x_out; int64_t ldo; bf16_t* xb; int64_t ldb;
+  int64_t M; int k_tiles; float eps;
+  int stagger;   // first-round workgroups on every other CU start this many s_sleep(127) periods (~4 us each) late
+};
+
+__device__ __forceinline__ float group4_sum(float v) {   // over the 4 lane groups (lanes l, l^16, l^32, l^48)
+  typedef uint32_t u32x2_sw __attribute__((ext_vector_type(2)));
+  u32x2_sw r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+__global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearLnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // waves w and w+4 share a SIMD; wm = 1 runs one phase behind
+  const int64_t m0 = (int64_t)blockIdx.x * FM;
+  // All tiles cost the same, so the CUs of a launch run in lockstep: every main loop at once (HBM idle), then every
+  // epilogue at once (768 KiB per tile against a 256th of the memory system).  Delaying the first-round workgroups of
+  // every other CU by half a tile puts one half's epilogues under the other half's main loops for the whole launch.
+  if (p.stagger > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1))
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+
+  const char* src_x;
+  const char* src_w[4];
+  {
+    const int row = tid >> 2, c = tid & 3;
+    int64_t gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    src_x = p.A + gm * p.lda_b + ((c ^ swz2_x(row)) << 4);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int id = r * FTHREADS + tid;
+    const int row = id >> 2, c = id & 3;
+    src_w[r] = p.W + (int64_t)row * p.ldw_b + ((c ^ swz2_w(row)) << 4);
+  }
+  auto stage = [&](int kt) {
+    const int64_t koff = (int64_t)kt * ROW2;
+    char* base = smem + (kt % FNST) * FSTAGE;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x + koff),
+                                     (lds_ptr_t)(base + (wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
+                                       (lds_ptr_t)(base + FOPER_X + (r * FTHREADS + wave * 64) * 16), 16, 0, 0);
+  };
+  const int i16 = lane & 15, g = lane >> 4;
+  int off_x[4], off_w[8];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int row = wm * 64 + 16 * f + i16;
+    off_x[f] = row * ROW2 + ((g ^ swz2_x(row)) << 4);
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {   // weight rows interleaved so that a lane ends up with 32 CONSECUTIVE output features
+    const int row = wn * 128 + 32 * (i16 >> 2) + 4 * f + (i16 & 3);
+    off_w[f] = FOPER_X + row * ROW2 + ((g ^ swz2_w(row)) << 4);
+  }
+  f32x4 acc[8][4];  // [fn][fm]: features wn*128 + 32g + 4fn .. +3 of row wm*64 + 16fm + i16
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nt = p.k_tiles;   // >= 3 (dispatch)
+  stage(0);
+  stage(1);
+  stage(2);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // stage 0 is complete
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
+
+  for (int s = 0; s < nt; ++s) {
+    u32x4 fw[8], fx[4];
+    {
+      const char* buf = smem + (s % FNST) * FSTAGE;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) fw[f] = *reinterpret_cast<const u32x4*>(buf + off_w[f]);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fx[f] = *reinterpret_cast<const u32x4*>(buf + off_x[f]);
+    }
+    if (s >= 1 && s + 2 < nt) stage(s + 2);   // into the buffer of stage s-1
+    if (s + 2 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // own pieces of stage s+1 have landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < 8; ++fn) acc[fn][fm] = Mma<bf16_t>::run(fw[fn], fx[fm], acc[fn][fm]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // the early half waits for the late half's last phase: the ring is dead
+  asm volatile("" ::: "memory");
+
+  // ---- bias, rounding to bf16 ----
+  const int nb = wn * 128 + 32 * g;
+#pragma unroll
+  for (int fn = 0; fn < 8; ++fn) {
+    const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb + 4 * fn) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+      const uint32_t lo = pack_bf16x2(acc[fn][fm].x + b4.x, acc[fn][fm].y + b4.y);
+      const uint32_t hi = pack_bf16x2(acc[fn][fm].z + b4.z, acc[fn][fm].w + b4.w);
+      acc[fn][fm] = f32x4{__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                          __uint_as_float(hi & 0xffff0000u)};
+    }
+  }
+  // ---- row statistics: two passes over the registers; partial sums of the four n-waves meet in LDS ----
+  float* const st_sum = reinterpret_cast<float*>(smem + 65536);   // [128 rows][4 n-waves]
+  float* const st_sq = st_sum + 512;
+  float* const st_mr = st_sq + 512 + wave * 128;                  // this wave's own copy: [64 rows][mean, rstd]
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    float t = 0.f;
+#pragma unroll
+    for (int fn = 0; fn < 8; ++fn) t += (acc[fn][fm].x + acc[fn][fm].y) + (acc[fn][fm].z + acc[fn][fm].w);
+    t = group4_sum(t);
+    if (g == 0) st_sum[(wm * 64 + 16 * fm + i16) * 4 + wn] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(st_sum + (wm * 64 + 16 * fm + i16) * 4);
+    mean[fm] = ((t.x + t.y) + (t.z + t.w)) * (1.0f / FN);
+    float q = 0.f;
+#pragma unroll
+    for (int fn = 0; fn < 8; ++fn) {
+      const float d0 = acc[fn][fm].x - mean[fm], d1 = acc[fn][fm].y - mean[fm], d2 = acc[fn][fm].z - mean[fm],
+                  d3 = acc[fn][fm].w - mean[fm];
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    q = group4_sum(q);
+    if (g == 0) st_sq[(wm * 64 + 16 * fm + i16) * 4 + wn] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(st_sq + (wm * 64 + 16 * fm + i16) * 4);
+    rstd[fm] = rsqrtf(((t.x + t.y) + (t.z + t.w)) * (1.0f / FN) + p.eps);
+    if (g == 0) {
+      st_mr[(16 * fm + i16) * 2] = mean[fm];
+      st_mr[(16 * fm + i16) * 2 + 1] = rstd[fm];
+    }
+  }
+  // ---- 16 rows at a time through this wave's 8 KiB: [16 rows][32 pieces of 16 B], piece P of row r at P ^ c(r) with
+  //      c(r) = r ^ 2 (r >> 2): conflict-free for the b128 writes (a lane writes pieces 8g..8g+7 of row i16) and for the
+  //      row-major b128 reads (two rows per instruction) under gfx950's 16-lane service groups ----
+  char* const mine = smem + wave * 8192;
+  const int L = lane & 31, half = lane >> 5;
+  const int col = wn * 128 + 4 * L;
+  f32x4 gn = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.gain) gn = *reinterpret_cast<const f32x4*>(p.gain + col);
+  if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+  const int cw = (i16 ^ ((i16 >> 2) << 1)) & 31;
+  // The residual rows of a 16-row pass are fetched one pass ahead, all eight loads of a lane at once: x_out may alias
+  // x_in, so a load written behind the previous row's store would have to wait for it -- 32 exposed round trips per tile.
+  f32x4 xr[2][8];
+  auto fetch_x = [&](int fm, f32x4 (&dst)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int64_t m = m0 + wm * 64 + 16 * fm + 2 * j + half;
+      m = m < p.M ? m : p.M - 1;
+      dst[j] = *reinterpret_cast<const f32x4*>(p.x_in + m * p.ldx + col);
+    }
+  };
+  fetch_x(0, xr[0]);
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+    if (fm + 1 < 4) fetch_x(fm + 1, xr[(fm + 1) & 1]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(mine + i16 * 512 + (((8 * g + q) ^ cw) << 4)) = acc[q][fm];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r16 = 2 * j + half;
+      const int cr = (r16 ^ ((r16 >> 2) << 1)) & 31;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(mine + r16 * 512 + ((L ^ cr) << 4));
+      const float mu = st_mr[(16 * fm + r16) * 2], rs = st_mr[(16 * fm + r16) * 2 + 1];
+      const int64_t m = m0 + wm * 64 + 16 * fm + r16;
+      if (m < p.M) {
+        const f32x4 x = xr[fm & 1][j];
+        f32x4 o;
+        o.x = fmaf((v.x - mu) * rs, gn.x, sh.x) + x.x;
+        o.y = fmaf((v.y - mu) * rs, gn.y, sh.y) + x.y;
+        o.z = fmaf((v.z - mu) * rs, gn.z, sh.z) + x.z;
+        o.w = fmaf((v.w - mu) * rs, gn.w, sh.w) + x.w;
+        *reinterpret_cast<f32x4*>(p.x_out + m * p.ldo + col) = o;
+        if (p.xb) *reinterpret_cast<u32x2*>(p.xb + m * p.ldb + col) = u32x2{pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
+      }
+    }
+  }
+}
+
 }  // namespace
 
 }  // namespace aurora
@@ -1775,4 +2000,36 @@ extern "C" int aurora_hip_split_f16(const float* src, int64_t ld_src, void* dst,
   hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), src, ld_src,
                      (char*)dst, ld_dst, rows, K, scale);
   return check_launch("split_f16");
+}
+
+extern "C" int aurora_hip_linear_layernorm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                           const float* gain, const float* shift, const float* x_in, int64_t ldx,
+                                           float* x_out, int64_t ldo, void* x_bf16, int64_t ldb, int64_t M, int N, int K,
+                                           float eps, void* stream) {
+  AURORA_CHECK_ARG(N == FN, "linear_layernorm: N=%d (only D = 512 rows are owned by one workgroup)", N);
+  AURORA_CHECK_ARG(M > 0 && K % 32 == 0 && K >= 96, "linear_layernorm: K=%d must be a multiple of 32, >= 96", K);
+  AURORA_CHECK_ARG(A && W && x_in && x_out && lda >= K && ldw >= K && (lda * 2) % 16 == 0 && (ldw * 2) % 16 == 0 &&
+                       ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0,
+                   "linear_layernorm: operand strides / alignment");
+  AURORA_CHECK_ARG(ldx >= N && ldo >= N && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x_in % 16) == 0 &&
+                       ((uintptr_t)x_out % 16) == 0 && (!x_bf16 || (ldb >= N && ldb % 4 == 0 && ((uintptr_t)x_bf16 % 8) == 0)),
+                   "linear_layernorm: residual / output strides / alignment");
+  AURORA_CHECK_ARG((!bias || ((uintptr_t)bias % 16) == 0) && (!gain || ((uintptr_t)gain % 16) == 0) &&
+                       (!shift || ((uintptr_t)shift % 16) == 0), "linear_layernorm: unaligned bias / gain / shift");
+  LinearLnArgs p{(const char*)A, lda * 2, (const char*)W, ldw * 2, bias, gain, shift, x_in, ldx, x_out, ldo, (bf16_t*)x_bf16, ldb,
+                 M, K / 32, eps, 0};
+  {
+    static const int stagger = [] { const char* e = getenv("AURORA_FUSED_STAGGER"); return e ? atoi(e) : 0; }();
+    p.stagger = stagger;
+  }
+  static bool attr_done_dev[64] = {false};
+  bool& attr_done = attr_done_dev[current_device() & 63];
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)linear_ln512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FNST * FSTAGE);
+    attr_done = true;
+  }
+  const int64_t blocks = (M + FM - 1) / FM;
+  AURORA_CHECK_ARG(blocks < (int64_t)1 << 31, "linear_layernorm: too many tiles");
+  hipLaunchKernelGGL(linear_ln512_kernel, dim3((unsigned)blocks), dim3(FTHREADS), FNST * FSTAGE, as_stream(stream), p);
+  return check_launch("linear_layernorm");
 }

@@ -313,10 +313,10 @@ typedef aurora_hip_model Model;
 // Kernel kinds of the per-launch timing; `work` is the algorithmic work of a launch: FLOPs for the linears, bytes
 // (q, k, v read + o written once) for the window attention, 0 elsewhere.
 enum Kind { K_LINEAR_BF16, K_LINEAR_F32, K_WINDOW_ATTENTION, K_LAYERNORM, K_MERGE_LN, K_SPLIT_LN, K_PATCHIFY,
-            K_PERCEIVER_ATTENTION, K_ASSEMBLE, K_UNPATCHIFY, K_COPY2D, K_ABSMAX, K_COUNT };
+            K_PERCEIVER_ATTENTION, K_ASSEMBLE, K_UNPATCHIFY, K_COPY2D, K_ABSMAX, K_LINEAR_LN, K_COUNT };
 const char* const KIND_NAMES[K_COUNT] = {"linear_bf16", "linear_f32", "window_attention_bf16", "layernorm", "merge_ln",
                                          "split_ln", "patchify", "perceiver_attention", "assemble_tokens", "unpatchify",
-                                         "copy2d", "absmax"};
+                                         "copy2d", "absmax", "linear_layernorm_bf16"};
 
 hipEvent_t take_event(Model& m) {
   if (!m.event_pool.empty()) {
@@ -815,17 +815,35 @@ float* run_step(Model& m, const StepIO& s, void* stream) {
                                            tb.has_grp ? (const uint8_t*)tb.grp.p : nullptr, B, Ls, Ls, dim, blk.heads,
                                            tb.n_windows, tb.n_tok, bb, stream);
       });
-      void* y = A.take((size_t)M * dim * es);
-      L.linear(ao, dim, aw.proj[bi], dim, blk.proj_b, y, dim, M, dim, dim, bb);
-      L.layernorm(y, dim, blk.gain1, blk.shift1, xf, dim, 0, xf, dim, xb, dim, M, dim, 1e-5f, bb);
+      // D = 512 under autocast: the linear, its AdaLN and the residual add are ONE launch (a workgroup owns whole rows)
+      static const bool fuse_env = [] { const char* e = getenv("AURORA_FUSE_LN"); return e ? atoi(e) != 0 : true; }();
+      const bool fuse = bf && dim == 512 && fuse_env;
+      auto fused = [&](const void* a, const void* w, const float* bias, int K_, const float* gain, const float* shift, float* xo,
+                       int64_t ldo, void* xbo) {
+        timed(m, stream, K_LINEAR_LN, 2.0 * (double)M * dim * K_, [&] {
+          return aurora_hip_linear_layernorm(a, K_, w, K_, bias, gain, shift, xf, dim, xo, ldo, xbo, dim, M, dim, K_, 1e-5f, stream);
+        });
+      };
+      if (fuse) {
+        fused(ao, aw.proj[bi], blk.proj_b, dim, blk.gain1, blk.shift1, xf, dim, xb);
+      } else {
+        void* y = A.take((size_t)M * dim * es);
+        L.linear(ao, dim, aw.proj[bi], dim, blk.proj_b, y, dim, M, dim, dim, bb);
+        L.layernorm(y, dim, blk.gain1, blk.shift1, xf, dim, 0, xf, dim, xb, dim, M, dim, 1e-5f, bb);
+      }
       A.top = mark;
       void* hid = A.take((size_t)M * blk.hidden * es);
       L.linear(a_in, dim, blk.fc1_w, dim, blk.fc1_b, hid, blk.hidden, M, blk.hidden, dim, bb, AURORA_ACT_GELU);
-      void* y2 = A.take((size_t)M * dim * es);
-      L.linear(hid, blk.hidden, blk.fc2_w, blk.hidden, blk.fc2_b, y2, dim, M, dim, blk.hidden, bb);
       const bool last = final_out != nullptr && k == count - 1;
-      L.layernorm(y2, dim, blk.gain2, blk.shift2, xf, dim, 0, last ? final_out : xf, last ? final_ld : dim, last ? nullptr : xb,
-                  dim, M, dim, 1e-5f, bb);
+      if (fuse) {
+        fused(hid, blk.fc2_w, blk.fc2_b, blk.hidden, blk.gain2, blk.shift2, last ? final_out : xf, last ? final_ld : dim,
+              last ? nullptr : xb);
+      } else {
+        void* y2 = A.take((size_t)M * dim * es);
+        L.linear(hid, blk.hidden, blk.fc2_w, blk.hidden, blk.fc2_b, y2, dim, M, dim, blk.hidden, bb);
+        L.layernorm(y2, dim, blk.gain2, blk.shift2, xf, dim, 0, last ? final_out : xf, last ? final_ld : dim, last ? nullptr : xb,
+                    dim, M, dim, 1e-5f, bb);
+      }
       A.top = mark;
     }
   };

@@ -979,18 +979,29 @@ class Engine:
                         lib.window_attention(qkv, blk["qkv.b"], ao, pl["tok"], pl["grp"], B, Ls + pl["n_halo"], dim,
                                              heads, L_out=Ls)
                 del qkv
-                y = lib.linear(ao, w_proj, blk["proj.b"], self.empty(M, dim, dtype=T_))
-                del ao
-                lib.layernorm(y, blk["norm1.gain"], blk["norm1.shift"], res=x_f, out_f32=x_f, out_t=x_b)
-                del y
+                # D = 512 under autocast: linear + AdaLN + residual in one launch (as the C-ABI handle sequences it)
+                fuse = bf and dim == 512 and os.environ.get("AURORA_FUSE_LN", "1") != "0"
+                if fuse:
+                    lib.linear_layernorm(ao, w_proj, blk["proj.b"], blk["norm1.gain"], blk["norm1.shift"], x_f, x_f, x_b)
+                    del ao
+                else:
+                    y = lib.linear(ao, w_proj, blk["proj.b"], self.empty(M, dim, dtype=T_))
+                    del ao
+                    lib.layernorm(y, blk["norm1.gain"], blk["norm1.shift"], res=x_f, out_f32=x_f, out_t=x_b)
+                    del y
                 hid = lib.linear(a_in, blk["fc1.w"], blk["fc1.b"], self.empty(M, blk["fc1.w"].shape[0], dtype=T_),
                                  act=lib.ACT_GELU)
-                y = lib.linear(hid, blk["fc2.w"], blk["fc2.b"], self.empty(M, dim, dtype=T_))
-                del hid
                 last = final_out is not None and bi == len(blocks) - 1
-                lib.layernorm(y, blk["norm2.gain"], blk["norm2.shift"], res=x_f,
-                              out_f32=final_out if last else x_f, out_t=None if last else x_b)
-                del y
+                if fuse:
+                    lib.linear_layernorm(hid, blk["fc2.w"], blk["fc2.b"], blk["norm2.gain"], blk["norm2.shift"], x_f,
+                                         final_out if last else x_f, None if last else x_b)
+                    del hid
+                else:
+                    y = lib.linear(hid, blk["fc2.w"], blk["fc2.b"], self.empty(M, dim, dtype=T_))
+                    del hid
+                    lib.layernorm(y, blk["norm2.gain"], blk["norm2.shift"], res=x_f,
+                                  out_f32=final_out if last else x_f, out_t=None if last else x_b)
+                    del y
             return x_f, x_b
 
         by_layer = lambda part, i: [b for b in self.blocks if b["part"] == part and b["layer"] == i]  # noqa: E731

@@ -55,6 +55,9 @@ _SIGNATURES = {
                                      c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                      c_int, c_int, c_void_p, c_float, c_void_p]),
     "aurora_hip_absmax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "aurora_hip_linear_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_float,
+                                            c_void_p]),
     "aurora_hip_split_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
     "aurora_hip_layernorm_split": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                            c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
@@ -317,6 +320,26 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
     return out
 
 
+def linear_layernorm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], gain: Optional[torch.Tensor],
+                     shift: Optional[torch.Tensor], x: torch.Tensor, x_out: torch.Tensor,
+                     x_bf16: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
+    """x_out = x + LN(a @ w.T + bias) * gain + shift, x_bf16 = bf16(x_out), in one launch (bf16 a / w, N = 512)."""
+    lda, K = _rows(a)
+    ldw, _ = _rows(w)
+    M, N = a.shape[0], w.shape[0]
+    assert a.dtype == w.dtype == torch.bfloat16 and x.dtype == x_out.dtype == torch.float32
+    ldx, _ = _rows(x)
+    ldo, _ = _rows(x_out)
+    ldb = 0
+    if x_bf16 is not None:
+        assert x_bf16.dtype == torch.bfloat16
+        ldb, _ = _rows(x_bf16)
+    with _Timed("linear_layernorm_bf16", 2.0 * M * N * K):
+        _check(load().aurora_hip_linear_layernorm(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), _ptr(gain), _ptr(shift), _ptr(x),
+                                                  ldx, _ptr(x_out), ldo, _ptr(x_bf16), ldb, M, N, K, eps, _stream()))
+    return x_out
+
+
 def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], out: torch.Tensor,
                      tok: torch.Tensor, grp: Optional[torch.Tensor], B: int, L: int, D: int,
                      heads: int, L_out: Optional[int] = None) -> torch.Tensor:
@@ -503,7 +526,7 @@ class HipProfileEntry(ctypes.Structure):
 
 
 PROFILE_KINDS = ("linear_bf16", "linear_f32", "window_attention_bf16", "layernorm", "merge_ln", "split_ln", "patchify",
-                 "perceiver_attention", "assemble_tokens", "unpatchify", "copy2d", "absmax")
+                 "perceiver_attention", "assemble_tokens", "unpatchify", "copy2d", "absmax", "linear_layernorm_bf16")
 
 _SIGNATURES.update({
     "aurora_hip_profile_begin": (c_int, [c_void_p, ctypes.c_uint32]),

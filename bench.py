@@ -46,8 +46,9 @@ LEVELS = (50, 100, 150, 200, 250, 300, 400, 500, 600, 700, 850, 925, 1000)
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (6.29 TB/s measured achievable)
 FLOP_PER_STEP = 96.8e12
-# A (M x K) + W (N x K) read once, C (M x N) written once, bf16, averaged over the 198 bf16 linears of a step
-ALGO_BYTES_PER_GEMM_LAUNCH = 579.0e6
+# A (M x K) + W (N x K) read once, C (M x N) written once, bf16, averaged over the 174 plain bf16 linears of a step
+# (the 24 stage-0 proj / fc2 launches run fused with their LayerNorm and are reported separately)
+ALGO_BYTES_PER_GEMM_LAUNCH = 530.5e6
 
 
 def synthetic_batch(cfg, H, W, seed, device, levels=LEVELS):
@@ -260,7 +261,7 @@ def main() -> None:
                                        "replicas": f"replica x{world} (independent forecasts, no data-path "
                                                    "collective)"}[mode]},
             "roofline": {
-                "kernel": "linear_kernel_256pp (bf16 MFMA GEMM, ping-pong LDS ring; all backbone linears)", "bound": "mfma",
+                "kernel": "linear_kernel_256pp (bf16 MFMA GEMM, ping-pong LDS ring; the 174 plain backbone linears of a step -- the 24 stage-0 proj / fc2 launches are fused with their AdaLN + residual: kernel_ms_per_step.linear_layernorm_bf16)", "bound": "mfma",
                 "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_source": f"profiles/{pmc[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command; "

@@ -131,6 +131,17 @@ int aurora_hip_layernorm(const void* y, int64_t ldy, const float* gain, const fl
                          const float* res, int64_t ldr, int64_t res_mod,
                          float* out_f32, int64_t ldo, void* out_t, int64_t ldt,
                          int64_t M, int D, float eps, int dtype, void* stream);
+/* bf16 linear + (adaptive) LayerNorm + residual in ONE launch, for N = D = 512 (stage 0 of the backbone):
+ *     x_out = x_in + LN(A W^T + bias) * gain + shift,     x_bf16 = bf16(x_out)   (nullable)
+ * i.e. `x = shortcut + norm1(proj(attn), c)` and `x = x + norm2(mlp(x), c)` of a Swin block (swin3d.py:507-508,
+ * film.py:38-49) without writing the linear's result to memory.  A, W bf16 (K contiguous, K % 32 == 0, K >= 96); the
+ * linear's result is rounded to bf16 before the statistics, as the reference's autocast linear is; fp32 statistics
+ * (two passes), fp32 residual stream; x_out may alias x_in.  One workgroup owns 128 whole rows. */
+int aurora_hip_linear_layernorm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                const float* gain, const float* shift,
+                                const float* x_in, int64_t ldx, float* x_out, int64_t ldo,
+                                void* x_bf16, int64_t ldb, int64_t M, int N, int K, float eps, void* stream);
+
 /* The same for fp32 rows, with the fp16-pair layout of the two-term GEMMs (see AURORA_F32_A_SPLIT) on either side: the
  * LayerNorm in front of a Perceiver MLP hands its result to fc1 already split (out_split; out_f32 may then be NULL),
  * and the LayerNorm behind the MLP takes that same array as its residual (res_is_split = 1: the residual value is
@@ -354,8 +365,8 @@ int64_t aurora_hip_workspace_bytes(const aurora_hip_model* model);
 
 /* Per-launch timing of the handle's own kernels: between _begin and _end every launch of a kernel kind whose bit is set
  * in kind_mask (bit i = entry i of the table _end returns: linear_bf16, linear_f32, window_attention_bf16, layernorm,
- * merge_ln, split_ln, patchify, perceiver_attention, assemble_tokens, unpatchify, copy2d, absmax) is bracketed by a HIP
- * event pair on the launch stream.  _end synchronises the device and fills `out` (capacity >= 12): launches, summed
+ * merge_ln, split_ln, patchify, perceiver_attention, assemble_tokens, unpatchify, copy2d, absmax, linear_layernorm_bf16) is
+ * bracketed by a HIP event pair on the launch stream.  _end synchronises the device and fills `out` (capacity >= 13): launches, summed
  * milliseconds and summed algorithmic work (FLOPs for the linears, bytes for the window attention) per kind.  This is
  * what bench.py's `roofline` is computed from.  An event pair keeps a launch from overlapping its neighbours. */
 typedef struct aurora_hip_profile_entry {

@@ -110,6 +110,36 @@ def test_linear_fp32_two_fp16_terms_full_epilogue(M, N, K, act):
     assert torch.isnan(out[:, N:]).all()
 
 
+@pytest.mark.parametrize("M,K", [(1000, 512), (5000, 2048), (128, 128), (66001, 512)])
+@pytest.mark.parametrize("in_place", [True, False])
+def test_linear_layernorm_fused_equals_the_two_kernels(M, K, in_place):
+    """bf16 linear + AdaLN + residual in one launch (D = 512) against linear -> layernorm: the same rounded linear result
+    enters the statistics, so the two differ by summation order only."""
+    L = lib()
+    N = 512
+    a = rnd(M, K, seed=1).bfloat16().to(DEV)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16().to(DEV)
+    b, gain, shift = (rnd(N, seed=s_).float().to(DEV) for s_ in (3, 4, 5))
+    x = (rnd(M, N, seed=6) * 2).float().to(DEV)
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    L.linear(a, w, b, y)
+    x_ref, xb_ref = torch.empty_like(x), torch.empty_like(y)
+    L.layernorm(y, gain, shift, res=x, out_f32=x_ref, out_t=xb_ref)
+    x_in = x.clone()
+    x_out = x_in if in_place else torch.full((M, N + 8), float("nan"), device=DEV)[:, :N]
+    xb = torch.empty_like(y) if in_place else None
+    L.linear_layernorm(a, w, b, gain, shift, x_in, x_out, xb)
+    torch.cuda.synchronize()
+    assert (x_out - x_ref).abs().max().item() < 2e-5
+    if xb is not None:
+        d = (xb.float() - xb_ref.float()).abs()
+        assert d.max().item() <= 0.0625 and (d > 0).float().mean().item() < 1e-3   # a bf16 ulp at a rounding boundary
+    else:
+        assert torch.equal(x_in, x)   # the input stream is untouched
+    with pytest.raises(ValueError):
+        L.linear_layernorm(a, w[:256], b, gain, shift, x_in, x_in, None)   # only N = 512 rows fit one workgroup
+
+
 def _unsplit(t):
     """fp16-pair layout -> (high halves, remainders) as fp32 tensors of the logical shape."""
     M, K = t.shape
