@@ -816,8 +816,14 @@ float* run_step(Model& m, const StepIO& s, void* stream) {
                                            tb.n_windows, tb.n_tok, bb, stream);
       });
       // D = 512 under autocast: the linear, its AdaLN and the residual add are ONE launch (a workgroup owns whole rows)
-      static const bool fuse_env = [] { const char* e = getenv("AURORA_FUSE_LN"); return e ? atoi(e) != 0 : true; }();
-      const bool fuse = bf && dim == 512 && fuse_env;
+      // AURORA_FUSE_LN: 0 never, 1 (default) by the fill rule below, 2 always (tests: read per step, not cached)
+      const char* fuse_e = getenv("AURORA_FUSE_LN");
+      const int fuse_env = fuse_e ? atoi(fuse_e) : 1;
+      // (a row-owning tile is 128 rows: only when the launch fills its rounds of one tile per CU -- a latitude band's
+      // 270 tiles on 256 CUs would take two rounds for the work of 1.05)
+      const int64_t ln_tiles = (M + 127) / 128, cus = device_cus();
+      const bool fills = (double)ln_tiles >= 0.85 * (double)(((ln_tiles + cus - 1) / cus) * cus);
+      const bool fuse = bf && dim == 512 && (fuse_env == 2 || (fuse_env == 1 && fills));
       auto fused = [&](const void* a, const void* w, const float* bias, int K_, const float* gain, const float* shift, float* xo,
                        int64_t ldo, void* xbo) {
         timed(m, stream, K_LINEAR_LN, 2.0 * (double)M * dim * K_, [&] {

@@ -980,7 +980,11 @@ class Engine:
                                              heads, L_out=Ls)
                 del qkv
                 # D = 512 under autocast: linear + AdaLN + residual in one launch (as the C-ABI handle sequences it)
-                fuse = bf and dim == 512 and os.environ.get("AURORA_FUSE_LN", "1") != "0"
+                # -- when the 128-row tiles fill their rounds of one tile per CU (a latitude band's 270 tiles on 256 CUs
+                # would take two rounds for the work of 1.05)
+                tiles, cus = -(-M // 128), torch.cuda.get_device_properties(self.device).multi_processor_count
+                fuse_env = os.environ.get("AURORA_FUSE_LN", "1")   # 0 never, 1 by the fill rule, 2 always (tests)
+                fuse = bf and dim == 512 and (fuse_env == "2" or (fuse_env == "1" and tiles >= 0.85 * (-(-tiles // cus) * cus)))
                 if fuse:
                     lib.linear_layernorm(ao, w_proj, blk["proj.b"], blk["norm1.gain"], blk["norm1.shift"], x_f, x_f, x_b)
                     del ao

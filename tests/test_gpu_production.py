@@ -99,6 +99,13 @@ def test_pretrained_default_geometry_matches_oracle():
     _compare(aurora_amd.AuroraPretrained, {}, 181, 360, LEVELS13)
 
 
+def test_pretrained_default_geometry_with_fused_adaln_matches_oracle(monkeypatch):
+    """The same with the stage-0 proj / fc2 linears fused with their AdaLN + residual (`linear_ln512_kernel`), which the
+    engine only picks by itself when the 128-row tiles fill the chip (the 0.25-degree grid; bench.py runs that)."""
+    monkeypatch.setenv("AURORA_FUSE_LN", "2")
+    _compare(aurora_amd.AuroraPretrained, {}, 181, 360, LEVELS13)
+
+
 def test_highres_default_geometry_matches_oracle():
     """AuroraHighRes(): patch size 10, depths (6,8,8)/(8,8,6), LoRA merged (single), on a 121 x 240 grid."""
     _compare(aurora_amd.AuroraHighRes, {}, 121, 240, LEVELS13)
