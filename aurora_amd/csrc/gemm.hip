@@ -1825,8 +1825,10 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
   // caller pairs it with a mode-1 launch on the fp32 weights carrying the same guard, which runs iff it does not.
   AURORA_CHECK_ARG(!pre || (dtype == AURORA_F32 && mode == 2 && N % VN == 0 && K % 32 == 0 && K >= 96),
                    "linear: fp16-pair operands need fp32, mode 2, N %% 256 == 0, K %% 32 == 0, K >= 96 (N=%d K=%d)", N, K);
-  AURORA_CHECK_ARG(!(pre & AURORA_F32_A_SPLIT) || ((pre & AURORA_F32_W_SPLIT) && guard == nullptr),
-                   "linear: a pre-split activation operand needs pre-split weights and takes no guard");
+  // (an A-split launch WITH a guard is for buffers whose format was itself decided by that guard on the device -- written
+  // as pairs by a guarded two-term producer iff it holds, as fp32 by its three-term twin otherwise)
+  AURORA_CHECK_ARG(!(pre & AURORA_F32_A_SPLIT) || (pre & AURORA_F32_W_SPLIT),
+                   "linear: a pre-split activation operand needs pre-split weights");
   AURORA_CHECK_ARG(!(pre & AURORA_F32_C_SPLIT) || (C2 == nullptr && ldc % 32 == 0 && ((uintptr_t)C % 16) == 0),
                    "linear: fp16-pair output needs ldc %% 32 == 0, 16-byte alignment and no second output");
   const float* const g_guard = (mode == 2 || (mode == 1 && dtype == AURORA_F32)) ? guard : nullptr;

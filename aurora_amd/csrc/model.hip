@@ -261,6 +261,9 @@ struct aurora_hip_model {
   DevBuf pos_scale, enc_bias, dec_queries, dec_q, stats;   // stats: loc | scale | inv per variable and level
   std::vector<size_t> surf_stat_off, static_stat_off, atmos_stat_off;   // float offsets into `stats`: loc, then scale, inv
   std::map<std::pair<int, int>, DevBuf> embed_w;           // (0 surf / 1 atmos, T) -> (D, Kpad) patch-embed GEMM weight
+  std::map<std::pair<int, int>, DevBuf> embed_ws;          // ... the same in the fp16-pair layout (scaled by 2^6), if eligible
+  std::map<std::pair<int, int>, float> embed_l1;           // ... its largest L1 row norm: |embedding| <= l1 * max|input| + |bias|
+  float enc_bias_max = 0.f;                                // max |atmospheric level bias| (precompute)
   DevBuf head_surf_w, head_surf_b, head_atmos_w, head_atmos_b;
   std::map<std::pair<int, int>, DevTables> tables;         // (stage, shifted)
   std::vector<Res> stage_res;
@@ -500,16 +503,23 @@ Resampler pack_resampler(Model& m, const std::string& prefix, int depth, int hea
 
 
 
+// What is known on the device about max |context| of a resampler: max|ctx| <= a * (*word) + c.  `pairs`: the context
+// buffer holds fp16 pairs iff *word < limit_kv (written so by a guarded two-term producer with that very guard), fp32 otherwise.
+struct CtxGuard { const float* word; float a, c, limit_kv; bool pairs; };
+
 // PerceiverResampler (perceiver.py:212-233) for all grid columns at once.  ctx: key j of column (b, l) at row
 // b*kv_bstride + j*kv_lstride + l.  First layer: latents (and so q) are shared by every column.  Returns (B*cols*Lq, D).
 float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, int64_t ctx_rows, int ctx_dim, const float* q0,
                  const float* latents0, int B, int64_t cols, int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads,
-                 float eps, size_t& out_mark) {
+                 float eps, size_t& out_mark, const CtxGuard* cg = nullptr) {
   const int64_t n_rows = (int64_t)B * cols * Lq;
   // The context is as unbounded as the model inputs, so the linears that read it, or averages of its value projection,
-  // pick their operand split on the device from max |ctx|.
-  float* ctx_max = m.ctx_max.f();
-  timed(m, L.stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(ctx, ctx_rows * ctx_dim, ctx_max, L.stream); });
+  // pick their operand split on the device: from max |ctx|, measured here, or from the bound the caller derived from a
+  // word it measured upstream (`cg`).
+  const float* ctx_max = cg ? cg->word : m.ctx_max.f();
+  const float g_a = cg ? cg->a : 1.0f, g_c = cg ? cg->c : 0.0f;
+  const bool ctx_pairs = cg && cg->pairs;
+  if (!cg) timed(m, L.stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(ctx, ctx_rows * ctx_dim, m.ctx_max.f(), L.stream); });
   float* lat = nullptr;
   for (size_t i = 0; i < rs.layers.size(); ++i) {
     const auto& ly = rs.layers[i];
@@ -522,16 +532,19 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     // guarded linears with pre-split weights: the two-term launch runs iff the guard holds, the three-term one (fp32
     // weights) iff it does not
     auto guarded = [&](const float* A, int64_t lda, const float* Wf, const void* Ws, float* C_, int64_t ldc, int64_t M_, int N_,
-                       int K_, float limit) {
+                       int K_, float limit, bool a_pairs = false) {
       if (Ws) {
-        L.linear(A, lda, Ws, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, 2 | AURORA_F32_W_SPLIT,
-                 ctx_max, limit);
+        L.linear(A, lda, Ws, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0,
+                 2 | AURORA_F32_W_SPLIT | (a_pairs ? AURORA_F32_A_SPLIT : 0), ctx_max, limit);
         L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, 1, ctx_max, limit);
       } else {
         L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, ly.f16_mode, ctx_max, limit);
       }
     };
-    guarded(ctx, ctx_dim, ly.to_kv, ly.to_kv_s, kv, 2 * inner, ctx_rows, 2 * inner, ctx_dim, F16_SAFE);
+    // |ctx| <= g_a * word + g_c < F16_SAFE  <=>  word < (F16_SAFE - g_c) / g_a; a context in pairs comes with its own limit
+    REQUIRE(!ctx_pairs || ly.to_kv_s, "resampler: a pair-layout context needs pre-split to_kv weights");
+    guarded(ctx, ctx_dim, ly.to_kv, ly.to_kv_s, kv, 2 * inner, ctx_rows, 2 * inner, ctx_dim,
+            ctx_pairs ? cg->limit_kv : (F16_SAFE - g_c) / g_a, ctx_pairs);
     if (ly.ln_k_w)   // LayerNorm over the K half, in place (perceiver.py:144-147)
       L.layernorm(kv, 2 * inner, ly.ln_k_w, ly.ln_k_b, nullptr, 0, 0, kv, 2 * inner, nullptr, 0, ctx_rows, inner, 1e-5f,
                   AURORA_F32);
@@ -549,7 +562,7 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
                                         AURORA_F32, L.stream); });
     float* o = (float*)m.arena.take((size_t)n_rows * Dd * 4);
     // |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
-    guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, F16_SAFE / ly.v_l1);
+    guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, (F16_SAFE / ly.v_l1 - g_c) / g_a);
     // The MLP in the fp16-pair layout end to end: the LayerNorm writes its result already split (and ONLY split), fc1
     // reads that and writes its GELU'd result split, fc2 reads that -- neither GEMM splits anything -- and the LayerNorm
     // behind the MLP takes the split array as its residual.
@@ -695,9 +708,29 @@ const float* embed_weight(Model& m, int kind, int T, int& K, int& Kpad) {
       for (int tt = 0; tt < T; ++tt)
         memcpy(&host[(size_t)d * Kpad + ((size_t)v * T + tt) * PP], &wv[((size_t)d * Tmax + tt) * PP], PP * sizeof(float));
   }
+  float l1 = 1e-6f, wmax = 0.f;
+  for (int d = 0; d < m.D; ++d) {
+    float sum = 0.f;
+    for (int k = 0; k < Kpad; ++k) {
+      const float a = fabsf(host[(size_t)d * Kpad + k]);
+      sum += a;
+      wmax = std::max(wmax, a);
+    }
+    l1 = std::max(l1, sum);
+  }
   DevBuf b = to_device(host);
+  m.embed_l1[key] = l1;
+  // the fp16-pair form for the guarded two-term kernel (the raw, normalised inputs are bounded only by the guard)
+  if (bounded_mode() == 2 && getenv("AURORA_NO_PRESPLIT") == nullptr && wmax < 1000.f && m.D % 256 == 0 && Kpad >= 96) {
+    DevBuf sp((size_t)m.D * Kpad * 4);
+    if (aurora_hip_split_f16(b.f(), Kpad, sp.p, Kpad, m.D, Kpad, 64.0f, nullptr) != AURORA_OK)
+      throw std::runtime_error(aurora_hip_last_error());
+    hip_ok(hipDeviceSynchronize(), "split embed weights");
+    m.embed_ws.emplace(key, std::move(sp));
+  }
   return m.embed_w.emplace(key, std::move(b)).first->second.f();
 }
+
 
 struct StepIO {
   const aurora_hip_step_io* io;
@@ -766,14 +799,39 @@ float* run_step(Model& m, const StepIO& s, void* stream) {
       });
     float* xa = (float*)A.take((size_t)C * B * Lp * D * 4);
     const int64_t R = (int64_t)B * Lp;
-    for (int c = 0; c < C; ++c)
-      L.linear(A_a + (size_t)c * R * Kpad_a, Kpad_a, w_a, Kpad_a, m.enc_bias.f() + (size_t)c * D, xa + (size_t)c * R * D, D, R, D,
-               Kpad_a, AURORA_F32);
+    // The patch embedding and the level aggregation's to_kv as one guarded chain: max |normalised input| is measured
+    // once (a third of the bytes of the embeddings the resampler would otherwise scan), and if it is inside fp16's range
+    // -- together with the bound it implies for the embeddings, |x| <= l1 * max|input| + max|bias| -- the embedding runs
+    // on two fp16 terms and writes fp16 PAIRS, which to_kv multiplies without splitting anything; otherwise both run on
+    // three bf16 terms over fp32 buffers.  One word and one limit decide format and kernels together.
+    const auto ekey = std::make_pair(1, T);
+    const void* w_a_s = m.embed_ws.count(ekey) ? m.embed_ws.at(ekey).p : nullptr;
+    bool chain = w_a_s != nullptr;
+    for (const auto& ly : m.enc_rs.layers) chain = chain && ly.f16_mode == 2 && ly.to_kv_s != nullptr;
+    CtxGuard cg{};
+    if (chain) {
+      float* word = m.ctx_max.f() + 1;
+      timed(m, stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(A_a, (int64_t)C * R * Kpad_a, word, stream); });
+      const float l1 = m.embed_l1.at(ekey), cb = m.enc_bias_max;
+      cg = CtxGuard{word, l1, cb, std::min(F16_SAFE, (F16_SAFE - cb) / l1), true};
+    }
+    for (int c = 0; c < C; ++c) {
+      const float* a_c = A_a + (size_t)c * R * Kpad_a;
+      const float* b_c = m.enc_bias.f() + (size_t)c * D;
+      float* x_c = xa + (size_t)c * R * D;
+      if (chain) {
+        L.linear(a_c, Kpad_a, w_a_s, Kpad_a, b_c, x_c, D, R, D, Kpad_a, AURORA_F32, 0, nullptr, 0, nullptr, 0,
+                 2 | AURORA_F32_W_SPLIT | AURORA_F32_C_SPLIT, cg.word, cg.limit_kv);
+        L.linear(a_c, Kpad_a, w_a, Kpad_a, b_c, x_c, D, R, D, Kpad_a, AURORA_F32, 0, nullptr, 0, nullptr, 0, 1, cg.word, cg.limit_kv);
+      } else {
+        L.linear(a_c, Kpad_a, w_a, Kpad_a, b_c, x_c, D, R, D, Kpad_a, AURORA_F32);
+      }
+    }
 
     // ---- level aggregation (Perceiver resampler over the level axis) ----
     size_t rs_mark = 0;
     float* lat = resampler(m, L, m.enc_rs, xa, (int64_t)C * R, D, m.enc_q0.f(), m.W("encoder.atmos_latents"), B, Lp, Lp, R,
-                           Cl - 1, C, m.perceiver_heads, m.ln_eps, rs_mark);
+                           Cl - 1, C, m.perceiver_heads, m.ln_eps, rs_mark, chain ? &cg : nullptr);
 
     // ---- assemble tokens + position / scale / time embeddings ----
     float* time_emb = (float*)A.take((size_t)B * D * 4);
@@ -1139,7 +1197,7 @@ extern "C" int aurora_hip_finalize(aurora_hip_model* mp, void* stream) {
   GUARDED({
     REQUIRE(mp != nullptr, "finalize: null model");
     Model& m = *mp;
-    m.keep.clear(); m.attn_sets.clear(); m.embed_w.clear(); m.merges.clear(); m.splits.clear();
+    m.keep.clear(); m.attn_sets.clear(); m.embed_w.clear(); m.embed_ws.clear(); m.embed_l1.clear(); m.merges.clear(); m.splits.clear();
     Launcher L{m, stream};
     const int D = m.D;
     // ---- AdaLN modulation of every block: lead time -> time_mlp -> stacked modulation linears (film.py:38-49) ----
@@ -1322,6 +1380,10 @@ extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid
         L.layernorm(m.dec_q.p, d0.inner, d0.ln_q_w, d0.ln_q_b, nullptr, 0, 0, m.dec_q.f(), d0.inner, nullptr, 0, C, d0.inner, 1e-5f,
                     AURORA_F32);
       hip_ok(hipStreamSynchronize(as_stream(stream)), "precompute sync");
+      std::vector<float> eb((size_t)C * D);
+      hip_ok(hipMemcpy(eb.data(), m.enc_bias.p, eb.size() * 4, hipMemcpyDeviceToHost), "download");
+      m.enc_bias_max = 0.f;
+      for (float v : eb) m.enc_bias_max = std::max(m.enc_bias_max, fabsf(v));
     }
     // ---- normalisation statistics: loc, scale, 1/scale (computed in fp64) per variable (and level) ----
     const int ns = (int)m.surf_vars.size(), nst = (int)m.static_vars.size(), na = (int)m.atmos_vars.size();

@@ -108,6 +108,7 @@ class Engine:
         self._table_cache: dict = {}
         self._ws_cache: dict = {}
         self._embed_w_cache: dict = {}
+        self._embed_extra: dict = {}
         self._stat_cache: dict = {}
         self._lora_sets: "OrderedDict[object, dict]" = OrderedDict()
         self.debug_hook = None  # optional callable(tag, tensor) at stage boundaries (tools/debug_blocks.py)
@@ -372,7 +373,7 @@ class Engine:
             dec = self._dev(encodings.levels(levels, D2))
             queries = self._linear_new(dec, self._p("decoder.atmos_levels_embed.weight"),
                                        self._p("decoder.atmos_levels_embed.bias"), D2)
-            out = dict(enc_bias=bias, dec_queries=queries)
+            out = dict(enc_bias=bias, dec_queries=queries, enc_bias_max=float(bias.abs().max().item()))
             for name, layers in self.dec_layers.items():
                 out[f"dec_q.{name}"] = self._linear_new(queries, layers[0]["to_q"], None, layers[0]["inner"])
             self._level_cache[levels] = out
@@ -416,6 +417,11 @@ class Engine:
             wp = torch.zeros((w.shape[0], Kpad), dtype=F32, device=self.device)
             wp[:, :K] = w
             self._embed_w_cache[key] = (wp, K)
+            # for the guarded two-term chain of the atmospheric embedding: largest L1 row norm (|embedding| <= l1 max|input| +
+            # |bias|) and the weight in the fp16-pair layout, if eligible
+            l1 = max(float(wp.abs().sum(dim=1).max().item()), 1e-6)
+            ok = float(wp.abs().max().item()) < 1000.0 and lib.presplit_ok(*wp.shape)
+            self._embed_extra[key] = (lib.split_f16(wp, scale=64.0) if ok else None, l1)
         return self._embed_w_cache[key]
 
     # ---------------------------------------------------------------------------------------
@@ -808,15 +814,38 @@ class Engine:
             lib.patchify(adescs[i:i + 32], A_a, i * T * P * P, K_a, B, T, C, Hp, Wp, P)
         xa = self.empty(C * B * L, D)
         R = B * L
+        # The patch embedding and the level aggregation's to_kv as one guarded chain (as csrc/model.hip sequences it):
+        # max |normalised input| is measured once; inside fp16's range -- together with the bound it implies for the
+        # embeddings, |x| <= l1 * max|input| + max|bias| -- the embedding runs on two fp16 terms and writes fp16 PAIRS,
+        # which to_kv multiplies without splitting anything; otherwise both run on three bf16 terms over fp32 buffers.
+        if cfg.level_condition:
+            ekeys = [(f"encoder.atmos_token_embeds.layers.{level_to_str(l_)}", atmos_names, T) for l_ in levels]
+        else:
+            ekeys = [("encoder.atmos_token_embeds", atmos_names, T)] * C
+        extras = [self._embed_extra[k] for k in ekeys]
+        chain = (lib.two_term_free() and all(e[0] is not None for e in extras)
+                 and all(ly["f16_ok"] and "to_kv.s" in ly for ly in self.enc_layers))
+        guard = None
+        if chain:
+            word = lib.absmax(A_a)
+            l1, cb = max(e[1] for e in extras), lv["enc_bias_max"]
+            guard = dict(word=word, a=l1, c=cb, limit_kv=min(_F16_SAFE, (_F16_SAFE - cb) / l1), pairs=True)
         for c in range(C):
-            lib.linear(A_a[c * R:(c + 1) * R], packs[c][0], lv["enc_bias"][c], xa[c * R:(c + 1) * R])
+            a_c, x_c = A_a[c * R:(c + 1) * R], xa[c * R:(c + 1) * R]
+            if chain:
+                with lib.f32_gemm(2, guard=(guard["word"], guard["limit_kv"])):
+                    lib.linear(a_c, extras[c][0], lv["enc_bias"][c], x_c, presplit=lib.F32_W_SPLIT | lib.F32_C_SPLIT)
+                with lib.f32_gemm(1, guard=(guard["word"], guard["limit_kv"])):
+                    lib.linear(a_c, packs[c][0], lv["enc_bias"][c], x_c)
+            else:
+                lib.linear(a_c, packs[c][0], lv["enc_bias"][c], x_c)
         del A_a
 
         # ---- level aggregation (Perceiver resampler over the level axis) ----
         n_lat = cfg.latent_levels - 1
         lat = self._resampler(self.enc_layers, xa, q0=self.enc_q0, latents0=self.enc_latents, B=B, cols=L,
                               kv_bstride=L, kv_lstride=B * L, Lq=n_lat, Lk=C, heads=cfg.num_heads,
-                              eps=cfg.perceiver_ln_eps)
+                              eps=cfg.perceiver_ln_eps, guard=guard)
         del xa
 
         # ---- assemble tokens + position / scale / time embeddings ----
@@ -831,7 +860,7 @@ class Engine:
         self._keepalive = keep
         return x_f, x_b
 
-    def _resampler(self, layers, ctx, *, q0, latents0, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, eps):
+    def _resampler(self, layers, ctx, *, q0, latents0, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, eps, guard=None):
         """PerceiverResampler (perceiver.py:212-233) for all grid columns at once.
 
         ctx: context rows, key j of column (b, l) at row b*kv_bstride + j*kv_lstride + l.
@@ -841,25 +870,31 @@ class Engine:
         n_rows = B * cols * Lq
         # The context is as unbounded as the model inputs (raw `randn` fields reach 4e6 here), so the linears that
         # read it, or averages of its value projection, pick their operand split on the device from max |ctx|.
-        ctx_max = lib.absmax(ctx)
+        # ... from max |ctx|, measured here, or from the bound the caller derived from a word it measured upstream
+        # (`guard`: max|ctx| <= a * word + c; `pairs`: ctx holds fp16 pairs iff word < limit_kv, fp32 otherwise)
+        ctx_max = guard["word"] if guard else lib.absmax(ctx)
+        g_a, g_c = (guard["a"], guard["c"]) if guard else (1.0, 0.0)
+        ctx_pairs = bool(guard and guard["pairs"])
         for i, ly in enumerate(layers):
             inner, hd = ly["inner"], ly["head_dim"]
             bounded = lib.bounded_activations if ly["f16_ok"] else (lambda guard=None: contextlib.nullcontext())
             pre = ly["f16_ok"] and lib.two_term_free()
 
-            def guarded(a, name, n_out, limit):
+            def guarded(a, name, n_out, limit, a_pairs=False):
                 """Guarded linear.  With pre-split weights: the two-term launch runs iff the guard holds, the three-term
                 one on the fp32 weights iff it does not (include/aurora_hip.h) -- the same result as the guarded call."""
                 if pre and name + ".s" in ly:
                     out = self.empty(a.shape[0], n_out)
                     with lib.f32_gemm(2, guard=(ctx_max, limit)):
-                        lib.linear(a, ly[name + ".s"], None, out, presplit=lib.F32_W_SPLIT)
+                        lib.linear(a, ly[name + ".s"], None, out,
+                                   presplit=lib.F32_W_SPLIT | (lib.F32_A_SPLIT if a_pairs else 0))
                     with lib.f32_gemm(1, guard=(ctx_max, limit)):
                         return lib.linear(a, ly[name], None, out)
                 with bounded(guard=(ctx_max, limit)):
                     return self._linear_new(a, ly[name], None, n_out)
 
-            kv = guarded(ctx, "to_kv", 2 * inner, _F16_SAFE)
+            assert not ctx_pairs or (pre and "to_kv.s" in ly)
+            kv = guarded(ctx, "to_kv", 2 * inner, guard["limit_kv"] if ctx_pairs else (_F16_SAFE - g_c) / g_a, ctx_pairs)
             if "ln_k.w" in ly:  # LayerNorm over the K half, in place (perceiver.py:144-147)
                 lib.layernorm(kv, ly["ln_k.w"], ly["ln_k.b"], out_f32=kv, d=inner)
             if i == 0:
@@ -874,7 +909,7 @@ class Engine:
             del kv
             D = ly["to_out"].shape[0]
             # |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
-            o = guarded(att, "to_out", D, _F16_SAFE / ly["v_l1"])
+            o = guarded(att, "to_out", D, (_F16_SAFE / ly["v_l1"] - g_c) / g_a)
             del att
             lat1 = self.empty(n_rows, D)   # fp32 values, or their fp16 pairs
             # The MLP in the fp16-pair layout end to end: LayerNorm writes its result already split (and only split),

@@ -86,7 +86,9 @@ int aurora_hip_default_f32_gemm(void);
  *   AURORA_F32_W_SPLIT: W is in the pair layout, scaled by 64.  With a guard the launch runs iff *guard < guard_limit
  *     and has NO fallback of its own: pair it with an f32_gemm = 1 call on the fp32 weights carrying the same guard
  *     (mode 1 with a guard runs iff the guard FAILS).
- *   AURORA_F32_A_SPLIT: A is in the pair layout (unscaled); needs AURORA_F32_W_SPLIT, takes no guard.
+ *   AURORA_F32_A_SPLIT: A is in the pair layout (unscaled); needs AURORA_F32_W_SPLIT.  With a guard it is for a buffer whose
+ *     FORMAT was decided by that same guard and limit on the device: written as pairs by a guarded two-term producer
+ *     (AURORA_F32_C_SPLIT) iff the guard holds, as fp32 by its mode-1 twin otherwise -- consumer and producer switch together.
  *   AURORA_F32_C_SPLIT: C is written in the pair layout (after bias / activation / residual); ldc % 32 == 0, no C2.
  * Shapes: N % 256 == 0, K % 32 == 0, K >= 96. */
 #define AURORA_F32_A_SPLIT 4

@@ -183,9 +183,6 @@ def test_linear_fp32_presplit_operands_are_bit_identical(M, N, K, act):
     # contract violations are refused, not mis-executed
     with pytest.raises(ValueError):
         L.linear(a_s, w, b, out, presplit=L.F32_A_SPLIT)             # pre-split activations need pre-split weights
-    with pytest.raises(ValueError):
-        with L.bounded_activations(guard=(L.absmax(a), 100.0)):
-            L.linear(a_s, ws, b, out, presplit=L.F32_W_SPLIT | L.F32_A_SPLIT)   # ... and take no guard
 
 
 @pytest.mark.parametrize("amax", [3.0, 1.0e6])
@@ -207,6 +204,35 @@ def test_linear_fp32_presplit_weights_guarded_pair(amax):
         L.linear(a, w, None, out)
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and torch.equal(out, base)
+
+
+@pytest.mark.parametrize("amax", [3.0, 1.0e6])
+def test_linear_fp32_guarded_chain_switches_format_and_kernels_together(amax):
+    """A guarded producer writes fp16 pairs iff the guard holds (its mode-1 twin fp32 otherwise) and the guarded consumer
+    reads the same buffer accordingly: the chain equals two guarded mode-2 linears on fp32 buffers, whatever the guard."""
+    L = lib()
+    M, K, D, N = 2050, 160, 512, 1024
+    a = (rnd(M, K, seed=31) * amax).float().to(DEV)
+    w1 = rnd(D, K, seed=32, scale=K ** -0.5).float().to(DEV)
+    w2 = rnd(N, D, seed=33, scale=D ** -0.5).float().to(DEV)
+    b1 = rnd(D, seed=34).float().to(DEV)
+    g = L.absmax(a)
+    limit = 1000.0
+    mid_ref, out_ref = torch.empty((M, D), device=DEV), torch.empty((M, N), device=DEV)
+    with L.bounded_activations(guard=(g, limit)):
+        L.linear(a, w1, b1, mid_ref)
+        L.linear(mid_ref, w2, None, out_ref)
+    w1s, w2s = L.split_f16(w1, scale=64.0), L.split_f16(w2, scale=64.0)
+    mid, out = torch.empty((M, D), device=DEV), torch.full((M, N), float("nan"), device=DEV)
+    with L.f32_gemm(2, guard=(g, limit)):
+        L.linear(a, w1s, b1, mid, presplit=L.F32_W_SPLIT | L.F32_C_SPLIT)            # pairs iff g < limit
+        L.linear(mid, w2s, None, out, presplit=L.F32_W_SPLIT | L.F32_A_SPLIT)
+    with L.f32_gemm(1, guard=(g, limit)):
+        L.linear(a, w1, b1, mid)                                                      # fp32 iff not
+        L.linear(mid, w2, None, out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.equal(out, out_ref)
+    assert torch.equal(mid, L.split_f16(mid_ref) if amax < limit else mid_ref)
 
 
 def test_layernorm_split_output():
