@@ -264,6 +264,11 @@ struct aurora_hip_model {
   std::map<std::pair<int, int>, DevBuf> embed_ws;          // ... the same in the fp16-pair layout (scaled by 2^6), if eligible
   std::map<std::pair<int, int>, float> embed_l1;           // ... its largest L1 row norm: |embedding| <= l1 * max|input| + |bias|
   float enc_bias_max = 0.f;                                // max |atmospheric level bias| (precompute)
+  // surface MLP behind the surface patch embedding, for its guarded two-term chain (finalize): pre-split weights, the
+  // largest L1 row norm and |bias| of its first linear, max |embedding bias| + max |level encoding|
+  DevBuf surf_w0_s, surf_w2_s;
+  float surf_l1_0 = 0.f, surf_b0 = 0.f, surf_c = 0.f;
+  bool surf_chain = false;
   DevBuf head_surf_w, head_surf_b, head_atmos_w, head_atmos_b;
   std::map<std::pair<int, int>, DevTables> tables;         // (stage, shifted)
   std::vector<Res> stage_res;
@@ -771,15 +776,37 @@ float* run_step(Model& m, const StepIO& s, void* stream) {
                                    K_s, B, T, 1, Hp, Wp, P, AURORA_F32, stream);
       });
     float* xs0 = (float*)A.take((size_t)B * Lp * D * 4);
-    L.linear(A_s, Kpad_s, w_s, Kpad_s, m.W("encoder.surf_token_embeds.bias"), xs0, D, B * Lp, D, Kpad_s, AURORA_F32, 0, nullptr,
-             0, m.W("encoder.surf_level_encoding"), 0);
     const int hid_s = (int)m.T_("encoder.surf_mlp.net.0.weight").shape[0];
     float* hid = (float*)A.take((size_t)B * Lp * hid_s * 4);
-    L.linear(xs0, D, m.W("encoder.surf_mlp.net.0.weight"), D, m.W("encoder.surf_mlp.net.0.bias"), hid, hid_s, B * Lp, hid_s, D,
-             AURORA_F32, AURORA_ACT_GELU);
     float* y = (float*)A.take((size_t)B * Lp * D * 4);
-    L.linear(hid, hid_s, m.W("encoder.surf_mlp.net.2.weight"), hid_s, m.W("encoder.surf_mlp.net.2.bias"), y, D, B * Lp, D, hid_s,
-             AURORA_F32);
+    // Guarded like the atmospheric chain: max |normalised input| once, then every linear takes two fp16 terms iff the
+    // bound that word implies for ITS activation operand is inside fp16's range -- embedding: the input itself; first
+    // MLP linear: |xs0| <= l1_e * w + c; second: |GELU(h)| <= |h| <= l1_0 * (l1_e * w + c) + |b0| -- else three bf16 terms.
+    const auto skey = std::make_pair(0, T);
+    const void* w_s_s = m.embed_ws.count(skey) ? m.embed_ws.at(skey).p : nullptr;
+    if (m.surf_chain && w_s_s) {
+      float* word = m.ctx_max.f() + 2;
+      timed(m, stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(A_s, (int64_t)B * Lp * Kpad_s, word, stream); });
+      const float l1e = m.embed_l1.at(skey);
+      const float lim_e = F16_SAFE, lim_0 = (F16_SAFE - m.surf_c) / l1e, lim_2 = ((F16_SAFE - m.surf_b0) / m.surf_l1_0 - m.surf_c) / l1e;
+      auto pair = [&](const float* a, int64_t lda, const float* wf, const void* ws, const float* bias, float* c, int64_t ldc, int N_,
+                      int K_, int act, const float* res, float limit) {
+        L.linear(a, lda, ws, K_, bias, c, ldc, B * Lp, N_, K_, AURORA_F32, act, nullptr, 0, res, 0, 2 | AURORA_F32_W_SPLIT, word, limit);
+        L.linear(a, lda, wf, K_, bias, c, ldc, B * Lp, N_, K_, AURORA_F32, act, nullptr, 0, res, 0, 1, word, limit);
+      };
+      pair(A_s, Kpad_s, w_s, w_s_s, m.W("encoder.surf_token_embeds.bias"), xs0, D, D, Kpad_s, 0, m.W("encoder.surf_level_encoding"), lim_e);
+      pair(xs0, D, m.W("encoder.surf_mlp.net.0.weight"), m.surf_w0_s.p, m.W("encoder.surf_mlp.net.0.bias"), hid, hid_s, hid_s, D,
+           AURORA_ACT_GELU, nullptr, lim_0);
+      pair(hid, hid_s, m.W("encoder.surf_mlp.net.2.weight"), m.surf_w2_s.p, m.W("encoder.surf_mlp.net.2.bias"), y, D, D, hid_s, 0,
+           nullptr, lim_2);
+    } else {
+      L.linear(A_s, Kpad_s, w_s, Kpad_s, m.W("encoder.surf_token_embeds.bias"), xs0, D, B * Lp, D, Kpad_s, AURORA_F32, 0, nullptr,
+               0, m.W("encoder.surf_level_encoding"), 0);
+      L.linear(xs0, D, m.W("encoder.surf_mlp.net.0.weight"), D, m.W("encoder.surf_mlp.net.0.bias"), hid, hid_s, B * Lp, hid_s, D,
+               AURORA_F32, AURORA_ACT_GELU);
+      L.linear(hid, hid_s, m.W("encoder.surf_mlp.net.2.weight"), hid_s, m.W("encoder.surf_mlp.net.2.bias"), y, D, B * Lp, D, hid_s,
+               AURORA_F32);
+    }
     L.layernorm(y, D, m.W("encoder.surf_norm.weight"), m.W("encoder.surf_norm.bias"), xs0, D, 0, y, D, nullptr, 0, B * Lp, D, 1e-5f,
                 AURORA_F32);   // xs0 + LN(MLP(xs0)), in place
     const float* xs1 = y;
@@ -1200,6 +1227,39 @@ extern "C" int aurora_hip_finalize(aurora_hip_model* mp, void* stream) {
     m.keep.clear(); m.attn_sets.clear(); m.embed_w.clear(); m.embed_ws.clear(); m.embed_l1.clear(); m.merges.clear(); m.splits.clear();
     Launcher L{m, stream};
     const int D = m.D;
+    {   // ---- surface MLP: constants of its guarded two-term chain ----
+      auto host_of = [&](const std::string& name) {
+        const Tensor& t = m.T_(name);
+        std::vector<float> h((size_t)t.numel);
+        hip_ok(hipMemcpy(h.data(), t.f(), h.size() * 4, hipMemcpyDeviceToHost), "download");
+        return h;
+      };
+      auto amax = [](const std::vector<float>& h) { float mx = 0.f; for (float v : h) mx = std::max(mx, fabsf(v)); return mx; };
+      const std::vector<float> w0 = host_of("encoder.surf_mlp.net.0.weight"), w2 = host_of("encoder.surf_mlp.net.2.weight");
+      const Tensor& t0 = m.T_("encoder.surf_mlp.net.0.weight");
+      const int64_t N0 = t0.shape[0], K0 = t0.shape[1];
+      m.surf_l1_0 = 1e-6f;
+      for (int64_t r = 0; r < N0; ++r) {
+        float sum = 0.f;
+        for (int64_t k = 0; k < K0; ++k) sum += fabsf(w0[(size_t)r * K0 + k]);
+        m.surf_l1_0 = std::max(m.surf_l1_0, sum);
+      }
+      m.surf_b0 = amax(host_of("encoder.surf_mlp.net.0.bias"));
+      m.surf_c = amax(host_of("encoder.surf_token_embeds.bias")) + amax(host_of("encoder.surf_level_encoding"));
+      auto eligible = [](int64_t N, int64_t K) { return N % 256 == 0 && K % 32 == 0 && K >= 96; };
+      m.surf_chain = bounded_mode() == 2 && getenv("AURORA_NO_PRESPLIT") == nullptr && amax(w0) < 1000.f && amax(w2) < 1000.f &&
+                     eligible(N0, K0) && eligible(K0, N0);
+      m.surf_w0_s = DevBuf();
+      m.surf_w2_s = DevBuf();
+      if (m.surf_chain) {
+        m.surf_w0_s = DevBuf((size_t)N0 * K0 * 4);
+        m.surf_w2_s = DevBuf((size_t)N0 * K0 * 4);
+        if (aurora_hip_split_f16(t0.f(), K0, m.surf_w0_s.p, K0, N0, (int)K0, 64.0f, nullptr) != AURORA_OK ||
+            aurora_hip_split_f16(m.T_("encoder.surf_mlp.net.2.weight").f(), N0, m.surf_w2_s.p, N0, K0, (int)N0, 64.0f, nullptr) != AURORA_OK)
+          throw std::runtime_error(aurora_hip_last_error());
+        hip_ok(hipDeviceSynchronize(), "split surface MLP weights");
+      }
+    }
     // ---- AdaLN modulation of every block: lead time -> time_mlp -> stacked modulation linears (film.py:38-49) ----
     std::vector<float> lead((size_t)D);
     const double hours = (double)(float)m.timestep_hours;

@@ -406,6 +406,21 @@ class Engine:
             self._stat_cache[key] = hit
         return hit[1], hit[2], hit[3]
 
+    def _surf_guard(self):
+        """Constants of the surface MLP's guarded two-term chain (None if its weights rule the split out): pre-split
+        weights, largest L1 row norm and |bias| of the first linear, max |embedding bias| + max |level encoding|."""
+        if not hasattr(self, "_surf_guard_cache"):
+            w0, w2 = self._p("encoder.surf_mlp.net.0.weight"), self._p("encoder.surf_mlp.net.2.weight")
+            ok = (float(w0.abs().max().item()) < 1000.0 and float(w2.abs().max().item()) < 1000.0
+                  and lib.presplit_ok(*w0.shape) and lib.presplit_ok(*w2.shape))
+            self._surf_guard_cache = None if not ok else dict(
+                w0_s=lib.split_f16(w0, scale=64.0), w2_s=lib.split_f16(w2, scale=64.0),
+                l1_0=max(float(w0.abs().sum(dim=1).max().item()), 1e-6),
+                b0=float(self._p("encoder.surf_mlp.net.0.bias").abs().max().item()),
+                c=float(self._p("encoder.surf_token_embeds.bias").abs().max().item())
+                + float(self._p("encoder.surf_level_encoding").abs().max().item()))
+        return self._surf_guard_cache
+
     def _embed_weight(self, prefix: str, names: tuple, T: int) -> tuple[torch.Tensor, int]:
         """(D, Kpad) GEMM weight of a LevelPatchEmbed for the given variable order / history."""
         key = (prefix, names, T)
@@ -793,10 +808,31 @@ class Engine:
         for i in range(0, len(descs), 32):
             lib.patchify(descs[i:i + 32], A_s, i * T * P * P, K_s, B, T, 1, Hp, Wp, P)
         sle = self._p("encoder.surf_level_encoding")[None].expand(B * L, D)  # stride-0 residual rows
-        xs0 = lib.linear(A_s, w_s, self._p("encoder.surf_token_embeds.bias"), self.empty(B * L, D), residual=sle)
-        hid = self._linear_new(xs0, self._p("encoder.surf_mlp.net.0.weight"), self._p("encoder.surf_mlp.net.0.bias"),
-                               self._sd["encoder.surf_mlp.net.0.weight"].shape[0], act=lib.ACT_GELU)
-        y = self._linear_new(hid, self._p("encoder.surf_mlp.net.2.weight"), self._p("encoder.surf_mlp.net.2.bias"), D)
+        w0, b0 = self._p("encoder.surf_mlp.net.0.weight"), self._p("encoder.surf_mlp.net.0.bias")
+        w2, b2 = self._p("encoder.surf_mlp.net.2.weight"), self._p("encoder.surf_mlp.net.2.bias")
+        be = self._p("encoder.surf_token_embeds.bias")
+        sg = self._surf_guard()
+        w_s_s, l1e = self._embed_extra[("encoder.surf_token_embeds", surf_names, T)]
+        if sg is not None and w_s_s is not None and lib.two_term_free():
+            # Guarded like the atmospheric chain (csrc/model.hip): max |normalised input| once; every linear takes two fp16
+            # terms iff the bound that word implies for ITS activation operand is inside fp16's range, else three bf16 terms.
+            word = lib.absmax(A_s)
+            lims = (_F16_SAFE, (_F16_SAFE - sg["c"]) / l1e, ((_F16_SAFE - sg["b0"]) / sg["l1_0"] - sg["c"]) / l1e)
+
+            def pair(a, wf, ws, bias, n_out, limit, **kw):
+                out = self.empty(a.shape[0], n_out)
+                with lib.f32_gemm(2, guard=(word, limit)):
+                    lib.linear(a, ws, bias, out, presplit=lib.F32_W_SPLIT, **kw)
+                with lib.f32_gemm(1, guard=(word, limit)):
+                    return lib.linear(a, wf, bias, out, **kw)
+
+            xs0 = pair(A_s, w_s, w_s_s, be, D, lims[0], residual=sle)
+            hid = pair(xs0, w0, sg["w0_s"], b0, w0.shape[0], lims[1], act=lib.ACT_GELU)
+            y = pair(hid, w2, sg["w2_s"], b2, D, lims[2])
+        else:
+            xs0 = lib.linear(A_s, w_s, be, self.empty(B * L, D), residual=sle)
+            hid = self._linear_new(xs0, w0, b0, w0.shape[0], act=lib.ACT_GELU)
+            y = self._linear_new(hid, w2, b2, D)
         xs1 = self.empty(B * L, D)
         lib.layernorm(y, self._p("encoder.surf_norm.weight"), self._p("encoder.surf_norm.bias"), res=xs0, out_f32=xs1)
         del hid, y, A_s
