@@ -159,9 +159,16 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
         uint32_t h0, h1, l0, l1;
         split_pair_f16(o[0], o[1], h0, l0);
         split_pair_f16(o[2], o[3], h1, l1);
-        char* d = reinterpret_cast<char*>(p.out_t) + (row * p.ldt + (e & ~31)) * 4 + (e & 31) * 2;
-        *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-        *reinterpret_cast<u32x2*>(d + 64) = u32x2{l0, l1};
+        // Lanes 2i and 2i+1 (features e..e+7 between them) trade halves -- the even lane ends up with the eight high halves,
+        // the odd lane with the eight remainders, 16 bytes each -- so that ONE store instruction covers every 128-byte
+        // group completely (four lanes the high half of the line, four the low half) instead of two instructions
+        // writing half a line each.
+        const bool odd = (lane & 1) != 0;
+        auto swap1 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true); };   // quad_perm [1,0,3,2]
+        const uint32_t r0 = swap1(odd ? h0 : l0), r1 = swap1(odd ? h1 : l1);
+        const int e8 = e & ~7;
+        char* d = reinterpret_cast<char*>(p.out_t) + (row * p.ldt + (e8 & ~31)) * 4 + (e8 & 31) * 2 + (odd ? 64 : 0);
+        *reinterpret_cast<u32x4*>(d) = odd ? u32x4{r0, r1, l0, l1} : u32x4{h0, h1, r0, r1};
       } else if (p.out_t) {
         store4(reinterpret_cast<T*>(p.out_t) + row * p.ldt + e, o);
       }
