@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
 struct PercArgs {
   const void* q; int64_t q_col_stride; const void* kv; void* out;
   int B; int64_t cols_per_b, kv_bstride, kv_lstride; int Lq, Lk, heads;
+  const float* pair_guard; float pair_limit;   // fp32 results leave as fp16 pairs iff *pair_guard < pair_limit (else fp32)
 };
 
 // A group of HDIM / 4 adjacent lanes owns one (grid column, head): each lane holds 4 of the head's features, so a
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs
   const int b = (int)(col / p.cols_per_b);
   const int64_t l = col - (int64_t)b * p.cols_per_b;
   const float scale = rsqrtf((float)HDIM);
+  const bool pairs = std::is_same<T, float>::value && p.pair_guard != nullptr && *p.pair_guard < p.pair_limit;   // (uniform)
   const T* kv0 = reinterpret_cast<const T*>(p.kv) + (b * p.kv_bstride + l) * (2 * (int64_t)inner) + h * HDIM + d0;
   const int64_t kv_step = p.kv_lstride * (2 * (int64_t)inner);
   // Queries are taken four at a time so that a column's keys / values are read once per chunk, not once per query.
@@ -166,7 +168,21 @@ __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs
       if (i0 + c < p.Lq) {
         const float inv = 1.0f / sum[c];
         const float r4[4] = {o[c][0] * inv, o[c][1] * inv, o[c][2] * inv, o[c][3] * inv};
-        store4(reinterpret_cast<T*>(p.out) + (col * p.Lq + i0 + c) * inner + h * HDIM + d0, r4);
+        if (pairs) {
+          // the fp16-pair layout of the two-term GEMM that reads this next (to_out): lanes 2i, 2i+1 hold 8 consecutive
+          // features between them and trade halves, the even lane stores the eight high halves, the odd one the remainders
+          uint32_t h0, h1, l0, l1;
+          split_pair_f16(r4[0], r4[1], h0, l0);
+          split_pair_f16(r4[2], r4[3], h1, l1);
+          const bool odd = (threadIdx.x & 1) != 0;
+          auto swap1 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true); };
+          const uint32_t s0 = swap1(odd ? h0 : l0), s1 = swap1(odd ? h1 : l1);
+          const int f8 = (h * HDIM + d0) & ~7;
+          char* d = reinterpret_cast<char*>(p.out) + ((col * p.Lq + i0 + c) * inner + (f8 & ~31)) * 4 + (f8 & 31) * 2 + (odd ? 64 : 0);
+          *reinterpret_cast<u32x4*>(d) = odd ? u32x4{s0, s1, l0, l1} : u32x4{h0, h1, s0, s1};
+        } else {
+          store4(reinterpret_cast<T*>(p.out) + (col * p.Lq + i0 + c) * inner + h * HDIM + d0, r4);
+        }
       }
     }
   }
@@ -305,9 +321,19 @@ extern "C" int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, voi
 extern "C" int aurora_hip_perceiver_attention(const void* q, int64_t q_col_stride, const void* kv, void* out,
                                               int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
                                               int Lq, int Lk, int heads, int head_dim, int dtype, void* stream) {
+  return aurora_hip_perceiver_attention_ex(q, q_col_stride, kv, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads,
+                                           head_dim, dtype, nullptr, 0.f, stream);
+}
+
+extern "C" int aurora_hip_perceiver_attention_ex(const void* q, int64_t q_col_stride, const void* kv, void* out,
+                                                 int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
+                                                 int Lq, int Lk, int heads, int head_dim, int dtype,
+                                                 const float* pair_guard, float pair_limit, void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "perceiver_attention: bad dtype");
   AURORA_CHECK_ARG(Lq > 0 && Lk > 0 && heads > 0 && B > 0 && cols_per_b > 0, "perceiver_attention: empty problem");
-  PercArgs p{q, q_col_stride, kv, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads};
+  AURORA_CHECK_ARG(pair_guard == nullptr || (dtype == AURORA_F32 && (heads * head_dim) % 32 == 0 && head_dim % 8 == 0),
+                   "perceiver_attention: fp16-pair output needs fp32 and heads * head_dim %% 32 == 0");
+  PercArgs p{q, q_col_stride, kv, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads, pair_guard, pair_limit};
   const int64_t items = (int64_t)B * cols_per_b * heads * (head_dim / 4);   // one lane per 4 features of a head
   const dim3 grid(blocks_for(items, 256)), block(256);
 #define AURORA_PERC(TT, HDIM) hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM>), grid, block, 0, as_stream(stream), p)

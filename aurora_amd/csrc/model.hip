@@ -563,11 +563,16 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
       q_stride = Lq;
     }
     float* att = (float*)m.arena.take((size_t)n_rows * inner * 4);
-    timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] { return aurora_hip_perceiver_attention(q, q_stride, kv, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim,
-                                        AURORA_F32, L.stream); });
+    // |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit.  With pre-split to_out
+    // weights the attention writes fp16 pairs iff that guard holds, and to_out multiplies them without splitting anything.
+    const float lim_out = (F16_SAFE / ly.v_l1 - g_c) / g_a;
+    const bool att_pairs = ly.to_out_s != nullptr && inner % 32 == 0;
+    timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] {
+      return aurora_hip_perceiver_attention_ex(q, q_stride, kv, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim,
+                                               AURORA_F32, att_pairs ? ctx_max : nullptr, lim_out, L.stream);
+    });
     float* o = (float*)m.arena.take((size_t)n_rows * Dd * 4);
-    // |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
-    guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, (F16_SAFE / ly.v_l1 - g_c) / g_a);
+    guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, lim_out, att_pairs);
     // The MLP in the fp16-pair layout end to end: the LayerNorm writes its result already split (and ONLY split), fc1
     // reads that and writes its GELU'd result split, fc2 reads that -- neither GEMM splits anything -- and the LayerNorm
     // behind the MLP takes the split array as its residual.

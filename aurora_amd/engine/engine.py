@@ -940,12 +940,16 @@ class Engine:
                 if "ln_q.w" in ly:
                     lib.layernorm(q, ly["ln_q.w"], ly["ln_q.b"], out_f32=q)
                 q_stride = Lq
+            # |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit.  With pre-split to_out
+            # weights the attention writes fp16 pairs iff that guard holds, and to_out multiplies them without splitting.
+            lim_out = (_F16_SAFE / ly["v_l1"] - g_c) / g_a
+            att_pairs = pre and "to_out.s" in ly and inner % 32 == 0
             att = lib.perceiver_attention(q, q_stride, kv, self.empty(n_rows, inner), B, cols, kv_bstride,
-                                          kv_lstride, Lq, Lk, heads, hd)
+                                          kv_lstride, Lq, Lk, heads, hd,
+                                          pair_guard=(ctx_max, lim_out) if att_pairs else None)
             del kv
             D = ly["to_out"].shape[0]
-            # |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit
-            o = guarded(att, "to_out", D, (_F16_SAFE / ly["v_l1"] - g_c) / g_a)
+            o = guarded(att, "to_out", D, lim_out, att_pairs)
             del att
             lat1 = self.empty(n_rows, D)   # fp32 values, or their fp16 pairs
             # The MLP in the fp16-pair layout end to end: LayerNorm writes its result already split (and only split),

@@ -80,6 +80,9 @@ _SIGNATURES = {
     "aurora_hip_perceiver_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64,
                                                c_int64, c_int64, c_int, c_int, c_int, c_int, c_int,
                                                c_void_p]),
+    "aurora_hip_perceiver_attention_ex": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64,
+                                                  c_int64, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                                  c_void_p, c_float, c_void_p]),
     "aurora_hip_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "aurora_hip_unpatchify": (c_int, [c_void_p, c_int64, ctypes.POINTER(UnpatchVar), c_int, c_int,
@@ -429,13 +432,15 @@ def patchify(desc: list[PatchVar], out: torch.Tensor, k_offset: int, k_total: in
 
 def perceiver_attention(q: torch.Tensor, q_col_stride: int, kv: torch.Tensor, out: torch.Tensor,
                         B: int, cols_per_b: int, kv_bstride: int, kv_lstride: int, Lq: int, Lk: int,
-                        heads: int, head_dim: int) -> torch.Tensor:
+                        heads: int, head_dim: int, pair_guard=None) -> torch.Tensor:
+    """`pair_guard=(word, limit)`: fp32 results are written as fp16 pairs iff word[0] < limit (decided on the device)."""
     assert q.is_contiguous() and kv.is_contiguous() and out.is_contiguous()
     assert q.dtype == kv.dtype == out.dtype
+    word, limit = pair_guard if pair_guard is not None else (None, 0.0)
     with _Timed("perceiver_attention", 0.0):
-        _check(load().aurora_hip_perceiver_attention(_ptr(q), q_col_stride, _ptr(kv), _ptr(out), B,
-                                                     cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads,
-                                                     head_dim, dtype_code(q.dtype), _stream()))
+        _check(load().aurora_hip_perceiver_attention_ex(_ptr(q), q_col_stride, _ptr(kv), _ptr(out), B,
+                                                        cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads,
+                                                        head_dim, dtype_code(q.dtype), _ptr(word), float(limit), _stream()))
     return out
 
 

@@ -212,6 +212,13 @@ int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, void* out, int
 int aurora_hip_perceiver_attention(const void* q, int64_t q_col_stride, const void* kv, void* out,
                                    int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
                                    int Lq, int Lk, int heads, int head_dim, int dtype, void* stream);
+/* The same with a device-side choice of the OUTPUT format (fp32 only): the rows are written as fp16 pairs (see
+ * AURORA_F32_A_SPLIT) iff *pair_guard < pair_limit, as fp32 otherwise -- the guard and limit of the guarded two-term
+ * linear that reads them next (to_out), so that producer, consumer and its three-term twin switch together. */
+int aurora_hip_perceiver_attention_ex(const void* q, int64_t q_col_stride, const void* kv, void* out,
+                                      int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
+                                      int Lq, int Lk, int heads, int head_dim, int dtype,
+                                      const float* pair_guard, float pair_limit, void* stream);
 
 /* ---- token assembly at the encoder output -------------------------------------------------
  * x[b][c][l][:] = (c == 0 ? surf[b][l][:] : agg[(b*L + l)*(Cl-1) + c-1][:])

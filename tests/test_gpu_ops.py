@@ -235,6 +235,21 @@ def test_linear_fp32_guarded_chain_switches_format_and_kernels_together(amax):
     assert torch.equal(mid, L.split_f16(mid_ref) if amax < limit else mid_ref)
 
 
+@pytest.mark.parametrize("holds", [True, False])
+def test_perceiver_attention_pair_output_follows_the_guard(holds):
+    L = lib()
+    B, cols, Lq, Lk, heads, hd = 1, 500, 13, 3, 16, 64
+    inner = heads * hd
+    q = rnd(Lq, inner, seed=1).float().to(DEV)
+    kv = rnd(Lk * cols, 2 * inner, seed=2).float().to(DEV)
+    ref = L.perceiver_attention(q, 0, kv, torch.empty(cols * Lq, inner, device=DEV), B, cols, cols * Lk, cols, Lq, Lk, heads, hd)
+    word = torch.tensor([1.0 if holds else 3.0], device=DEV)
+    out = L.perceiver_attention(q, 0, kv, torch.empty(cols * Lq, inner, device=DEV), B, cols, cols * Lk, cols, Lq, Lk, heads, hd,
+                                pair_guard=(word, 2.0))
+    torch.cuda.synchronize()
+    assert torch.equal(out, L.split_f16(ref) if holds else ref)
+
+
 def test_layernorm_split_output():
     L = lib()
     M, D = 1000, 1024
