@@ -63,6 +63,13 @@ class Shard:
     gather_output: bool = True    # True: forward() returns the full fields on every rank
 
 
+def fused_ln_fills(rows: int, cus: int) -> bool:
+    """Does a launch of the row-owning linear + LayerNorm kernel (128 x 512 tiles, one per CU and round) fill its rounds to
+    at least 85 %?  (The rule of csrc/model.hip: 2,025 tiles on 256 CUs do, a latitude band's 270 do not.)"""
+    tiles = -(-rows // 128)
+    return tiles >= 0.85 * (-(-tiles // cus) * cus)
+
+
 _F16_SAFE = 16384.0   # activations below this may take the two-term fp16 operand split (fp16 overflows at 65504)
 
 
@@ -1057,9 +1064,9 @@ class Engine:
                 # D = 512 under autocast: linear + AdaLN + residual in one launch (as the C-ABI handle sequences it)
                 # -- when the 128-row tiles fill their rounds of one tile per CU (a latitude band's 270 tiles on 256 CUs
                 # would take two rounds for the work of 1.05)
-                tiles, cus = -(-M // 128), torch.cuda.get_device_properties(self.device).multi_processor_count
+                cus = torch.cuda.get_device_properties(self.device).multi_processor_count
                 fuse_env = os.environ.get("AURORA_FUSE_LN", "1")   # 0 never, 1 by the fill rule, 2 always (tests)
-                fuse = bf and dim == 512 and (fuse_env == "2" or (fuse_env == "1" and tiles >= 0.85 * (-(-tiles // cus) * cus)))
+                fuse = bf and dim == 512 and (fuse_env == "2" or (fuse_env == "1" and fused_ln_fills(M, cus)))
                 if fuse:
                     lib.linear_layernorm(ao, w_proj, blk["proj.b"], blk["norm1.gain"], blk["norm1.shift"], x_f, x_f, x_b)
                     del ao
