@@ -54,3 +54,32 @@ def test_argument_errors_surface_without_a_gpu(built):
     assert code == -1 and b"multiple" in shim.load().aurora_hip_last_error()
     code = shim.load().aurora_hip_window_attention(16, None, 16, 16, None, 1, 10, 10, 96, 2, 1, 4, 1, None)
     assert code == -1 and b"head_dim" in shim.load().aurora_hip_last_error()
+
+
+def test_constants_and_new_argument_contracts_match_the_header(built):
+    """Flag values and profile-table length of the Python shim equal the header's; the argument contracts of the
+    round-2 entry points (pre-split operands, fused linear + LayerNorm, pair-layout LayerNorm) fail before any launch."""
+    from aurora_amd.engine import lib as shim
+
+    header = (ROOT / "include" / "aurora_hip.h").read_text()
+    defines = {k: int(v) for k, v in re.findall(r"#define (AURORA_F32_[ACW]_SPLIT) (\d+)", header)}
+    assert defines == {"AURORA_F32_A_SPLIT": shim.F32_A_SPLIT, "AURORA_F32_W_SPLIT": shim.F32_W_SPLIT,
+                       "AURORA_F32_C_SPLIT": shim.F32_C_SPLIT}
+    assert f"capacity >= {len(shim.PROFILE_KINDS)}" in header
+    for kind in shim.PROFILE_KINDS:
+        assert kind in header, kind
+    L = shim.load()
+    err = lambda: L.aurora_hip_last_error()  # noqa: E731
+    # pre-split operands: two-term mode only, N % 256 == 0, K % 32 == 0, K >= 96; a pre-split A needs a pre-split W
+    args = lambda N, K, mode: (16, K, 16, K, None, 16, N, None, 0, None, 0, 512, N, K, 0, 0, mode, None, 0.0, None)  # noqa: E731
+    assert L.aurora_hip_linear_ex(*args(512, 128, 2 | shim.F32_A_SPLIT)) == -1 and b"pre-split weights" in err()
+    assert L.aurora_hip_linear_ex(*args(512, 64, 2 | shim.F32_W_SPLIT)) == -1 and b"fp16-pair" in err()
+    assert L.aurora_hip_linear_ex(*args(80, 128, 2 | shim.F32_W_SPLIT)) == -1 and b"fp16-pair" in err()
+    assert L.aurora_hip_linear_ex(*args(512, 128, 1 | shim.F32_W_SPLIT)) == -1
+    # fused linear + LayerNorm: rows of 512 only
+    assert L.aurora_hip_linear_layernorm(16, 512, 16, 512, None, None, None, 16, 1024, 16, 1024, None, 0, 256, 1024, 512,
+                                         1e-5, None) == -1 and b"512" in err()
+    # pair-layout LayerNorm: D and the pair strides in multiples of 32
+    assert L.aurora_hip_layernorm_split(16, 48, None, None, None, 0, 0, 0, None, 0, 16, 48, 4, 48, 1e-5, None) == -1
+    assert L.aurora_hip_split_f16(16, 48, 16, 48, 4, 48, 1.0, None) == -1 and b"32" in err()
+    assert L.aurora_hip_perceiver_attention_ex(16, 0, 16, 16, 1, 4, 4, 1, 3, 3, 3, 16, 1, 16, 1.0, None) == -1
