@@ -78,7 +78,7 @@ __device__ __forceinline__ u32x4 pair_rows(u32x2 a, u32x2 b) {
 
 // FULL: the window has exactly 144 tokens (every stage of the published 0.25 / 0.1 / 0.4 degree
 // configurations): tile counts become compile-time constants.
-template <bool FULL, int WIDE>   // WIDE: 0 8-byte result stores, 1 16-byte, 2 16-byte covering whole 128-byte rows
+template <bool FULL, int WIDE>   // WIDE: 1 16-byte result stores, 2 16-byte stores covering whole 128-byte rows
 __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * MAXN * 128 + MAXN * 4 + MAXN + 16];
   char* const s_k = smem;                 // [144][128 B], 16-byte pieces XOR-swizzled by row & 7
@@ -280,7 +280,8 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
       const int col_a = col_q + (upper ? 32 : 0) + piece, col_b = col_a;
       if (l_a) *reinterpret_cast<u32x4*>(out + t_a * p.D + col_a) = upper ? got : v0;
       if (l_b) *reinterpret_cast<u32x4*>(out + t_b * p.D + col_b) = upper ? v1 : got;
-    } else if constexpr (WIDE == 1) {
+    } else {
+      static_assert(WIDE == 1, "WIDE is 1 or 2");
       // The C fragment gives a lane 4 consecutive d (8 bytes) per d-tile.  Lanes g, g^1 trade halves of two d-tiles so
       // that every lane stores 16 bytes and four lanes cover 64 contiguous bytes of the output row.
       const bool odd = (g & 1) != 0;
@@ -290,282 +291,7 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
         const int col = col_q + 32 * a + (odd ? 16 + 4 * (g - 1) : 4 * g);
         if (live) *reinterpret_cast<u32x4*>(out + (int64_t)tq * p.D + col) = v;
       }
-    } else {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const u32x2 packed = pv(dt);
-        if (live) *reinterpret_cast<u32x2*>(out + (int64_t)tq * p.D + col_q + dt * 16 + 4 * g) = packed;
-      }
     }
-  }
-}
-
-// ---- persistent, software-pipelined bf16 kernel (the one in use) -------------------------------------
-// The kernel above is latency-bound, not bandwidth-bound: a workgroup loads (2-3 us under load), stages, multiplies and
-// stores strictly in sequence, only four workgroups fit a CU (36 KiB of LDS each), and its waves are parked on
-// s_waitcnt / barriers for half of their life (SQ_WAIT_ANY 48 % of SQ_WAVE_CYCLES) -- 3.7 TB/s.  Here a workgroup
-// walks over (window, head) items with a grid stride and keeps the NEXT item's loads in flight while the current one is
-// multiplied out of LDS: its 12 K / V pieces per thread are issued before the current item's first MFMA (48 VGPRs),
-// its Q fragments take over the registers of the current Q tile as soon as that tile's S^T is done.  The window tables
-// (token ids, mask groups) travel two items ahead through two small LDS slots, so no load ever waits for a load.
-// Co-running workgroups b .. b+7 hold the heads of the same windows, i.e. adjacent 128-byte pieces of the same rows.
-// WIDE: lanes g and g^1 (lane ^ 16) trade halves of two 16-wide d-tiles so that every lane stores 16 bytes and four
-// lanes cover 64 contiguous bytes of an output row (the plain C fragment gives 8-byte stores, 32 bytes per row).
-template <bool FULL, bool WIDE>
-__global__ __launch_bounds__(192, 3) void window_attention_bf16_pipe(const AttnArgs p, const int total) {
-  constexpr int TABN = 192;               // table slots hold one entry per thread (only the first 144 are read)
-  __shared__ __attribute__((aligned(16))) char smem[2 * MAXN * 128 + 2 * TABN * 4 + 2 * TABN + 16];
-  char* const s_k = smem;                 // [144][128 B], 16-byte pieces XOR-swizzled by row & 7
-  char* const s_v = smem + MAXN * 128;    // same image for V; transposed on READ (ds_read_b64_tr_b16)
-  int32_t* const s_tok = reinterpret_cast<int32_t*>(smem + 2 * MAXN * 128);   // [2][192] token ids of two items
-  uint8_t* const s_grp = reinterpret_cast<uint8_t*>(s_tok + 2 * TABN);        // [2][192] mask groups
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i16 = lane & 15, g = lane >> 4;
-  const int N = FULL ? MAXN : p.N, nt = FULL ? MAXT : (N + 15) >> 4;
-  const int D3 = 3 * p.D;
-  const int G = gridDim.x;
-  constexpr int PIECES = MAXN * 8 / 192;
-
-  // Every prefetched register is CONSUMED on every path (`used`): hipcc's waitcnt insertion is a dataflow over the
-  // control-flow graph, and one path on which a pending load's destination is never read (a wave whose lanes all take
-  // the padded-row branch, threads beyond the table) makes it drain the whole queue (vmcnt(0)) before that register is
-  // written again -- right after the next item's loads were issued, which would serialise the pipeline.
-  auto used = [](auto v) { asm volatile("" ::"v"(v)); };
-  // this thread's entries of an item's window tables (-2: position beyond the window, zeros); unconditional loads
-  auto fetch_tab = [&](int item, int& tv, int& gv) {
-    const int w = (item / p.heads) % p.n_windows;
-    const int i = tid < N ? tid : N - 1;
-    tv = p.tok[(int64_t)w * N + i];
-    gv = p.grp ? (int)p.grp[(int64_t)w * N + i] : 0;
-  };
-  auto put_tab = [&](int slot, int tv, int gv) {
-    s_tok[slot * TABN + tid] = tid < N ? tv : -2;
-    s_grp[slot * TABN + tid] = (uint8_t)(tid < N ? gv : 0);
-  };
-  auto patch = [&](u32x4 v, int t, int col) -> u32x4 {
-    used(v);
-    if (t >= 0) return v;
-    if (t == -1 && p.bias) {   // padded window position: what Linear(0) yields
-      float bb[8];
-      load8(p.bias + col, bb);
-      return u32x4{pack_bf16x2(bb[0], bb[1]), pack_bf16x2(bb[2], bb[3]), pack_bf16x2(bb[4], bb[5]), pack_bf16x2(bb[6], bb[7])};
-    }
-    return u32x4{0u, 0u, 0u, 0u};
-  };
-  auto rows_of = [&](int item) {
-    return reinterpret_cast<const bf16_t*>(p.qkv) + (int64_t)(item / (p.heads * p.n_windows)) * p.L * D3;
-  };
-  // the 6 K + 6 V pieces of one item (clamped rows; padded / absent rows are patched when staged)
-  // (`opaque(tid)`: the staging offsets are loop invariants that LICM would otherwise park in ~20 VGPRs for the whole
-  // item loop -- and spill; recomputing them per item costs a handful of VALU operations)
-  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
-  auto issue_kv = [&](int item, int slot, u32x4 (&kreg)[PIECES], u32x4 (&vreg)[PIECES]) {
-    const bf16_t* const qkv = rows_of(item);
-    const int h = item % p.heads;
-    const int tid_l = opaque(tid);
-#pragma unroll
-    for (int it = 0; it < PIECES; ++it) {
-      const int idx = tid_l + it * 192, row = idx >> 3, c = idx & 7;
-      if (!FULL && row >= nt * 16) continue;
-      const int t = s_tok[slot * TABN + row];
-      const bf16_t* const src = qkv + (int64_t)(t < 0 ? 0 : t) * D3 + h * HD + c * 8;
-      kreg[it] = *reinterpret_cast<const u32x4*>(src + p.D);
-      vreg[it] = *reinterpret_cast<const u32x4*>(src + 2 * p.D);
-    }
-  };
-  auto issue_q = [&](int item, int slot, int j, u32x4 (&q)[2]) {
-    if (wave + 3 * j >= nt) return;
-    const int lane_l = opaque(lane);
-    const int t = s_tok[slot * TABN + (wave + 3 * j) * 16 + (lane_l & 15)];
-    const bf16_t* const src = rows_of(item) + (int64_t)(t < 0 ? 0 : t) * D3 + (item % p.heads) * HD + (lane_l >> 4) * 8;
-    q[0] = *reinterpret_cast<const u32x4*>(src);
-    q[1] = *reinterpret_cast<const u32x4*>(src + 32);
-  };
-  auto stage = [&](int item, int slot, const u32x4 (&kreg)[PIECES], const u32x4 (&vreg)[PIECES]) {
-    const int h = item % p.heads;
-    const int col_k = p.D + h * HD, col_v = 2 * p.D + h * HD;
-    const int tid_l = opaque(tid);
-#pragma unroll
-    for (int it = 0; it < PIECES; ++it) {
-      const int idx = tid_l + it * 192, row = idx >> 3, c = idx & 7;
-      if (!FULL && row >= nt * 16) continue;
-      const int t = s_tok[slot * TABN + row];
-      const int off = row * 128 + ((c ^ (row & 7)) << 4);
-      *reinterpret_cast<u32x4*>(s_k + off) = patch(kreg[it], t, col_k + c * 8);
-      *reinterpret_cast<u32x4*>(s_v + off) = patch(vreg[it], t, col_v + c * 8);
-    }
-  };
-  auto differs = [&](int slot) -> int {   // does this window really mix mask groups?
-    return (p.grp && tid < N) ? (s_grp[slot * TABN + tid] != s_grp[slot * TABN]) : 0;
-  };
-
-  // Per-lane LDS offsets (see the kernel above).
-  const int koff0 = i16 * 128 + ((g ^ (i16 & 7)) << 4), koff1 = i16 * 128 + (((g + 4) ^ (i16 & 7)) << 4);
-  int voff[4];
-  {
-    const int key = 4 * g + (i16 >> 2), q = i16 & 3;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      voff[dt] = key * 128 + (((2 * dt + (q >> 1)) ^ (key & 7)) << 4) + (q & 1) * 8;
-  }
-  const float c_scale = 0.125f * LOG2E;  // 1/sqrt(64), in the exp2 domain
-
-  int item = blockIdx.x;
-  if (item >= total) return;
-  bool has_next = item + G < total;
-  int slot = 0;
-  {
-    int tv, gv;
-    fetch_tab(item, tv, gv);
-    put_tab(0, tv, gv);
-    if (has_next) {
-      fetch_tab(item + G, tv, gv);
-      put_tab(1, tv, gv);
-    }
-  }
-  __syncthreads();
-  u32x4 kreg[PIECES], vreg[PIECES], qreg[3][2];
-  issue_kv(item, 0, kreg, vreg);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) issue_q(item, 0, j, qreg[j]);
-  stage(item, 0, kreg, vreg);
-  bool masked = __syncthreads_or(differs(0)) != 0;
-
-  for (;;) {
-    const int col_q = (item % p.heads) * HD;
-    bf16_t* const out = reinterpret_cast<bf16_t*>(p.out) + (int64_t)(item / (p.heads * p.n_windows)) * p.L_out * p.D;
-    const uint8_t* const grp = s_grp + slot * TABN;
-    int tqs[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) tqs[j] = (wave + 3 * j) * 16 + i16 < MAXN ? s_tok[slot * TABN + (wave + 3 * j) * 16 + i16] : -2;
-    // (settle this item's Q fragments first: everything older than the loads issued next is then known to be complete,
-    // and nothing inside the multiplication has to wait on the vector-memory counter)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      used(qreg[j][0]);
-      used(qreg[j][1]);
-    }
-    // the next item's K / V pieces: in flight while this item is multiplied
-    if (has_next) issue_kv(item + G, slot ^ 1, kreg, vreg);
-    const bool has_nn = item + 2 * G < total;
-    int tv_nn = -2, gv_nn = 0;
-    if (has_nn) fetch_tab(item + 2 * G, tv_nn, gv_nn);
-    __builtin_amdgcn_sched_barrier(0);
-
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int qt = wave + 3 * j;
-      if (qt >= nt) break;
-      const int tq = tqs[j];  // -2 beyond N
-      // ---- S^T tiles: keys along registers, this lane's query along lanes ----
-      f32x4 st[MAXT];
-      {
-        const u32x4 qf0 = patch(qreg[j][0], tq, col_q + g * 8), qf1 = patch(qreg[j][1], tq, col_q + 32 + g * 8);
-#pragma unroll
-        for (int kt = 0; kt < MAXT; ++kt) {
-          st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (FULL || kt < nt) {
-            const u32x4 k0 = *reinterpret_cast<const u32x4*>(s_k + kt * 2048 + koff0);
-            const u32x4 k1 = *reinterpret_cast<const u32x4*>(s_k + kt * 2048 + koff1);
-            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k0),
-                                                             __builtin_bit_cast(bf16x8_t, qf0), st[kt], 0, 0, 0);
-            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k1),
-                                                             __builtin_bit_cast(bf16x8_t, qf1), st[kt], 0, 0, 0);
-          }
-        }
-      }
-      // this tile's Q registers are free: the next item's Q tile j takes them over
-      if (has_next) issue_q(item + G, slot ^ 1, j, qreg[j]);
-
-      // ---- softmax over the keys of this lane's query, in the exp2 domain ----
-      if (masked) {
-        const uint32_t gq4 = (uint32_t)grp[qt * 16 + i16] * 0x01010101u;
-#pragma unroll
-        for (int kt = 0; kt < MAXT; ++kt) {
-          if (FULL || kt < nt) {
-            const uint32_t x = *reinterpret_cast<const uint32_t*>(grp + kt * 16 + 4 * g) ^ gq4;
-            st[kt].x += (x & 0x000000ffu) ? -100.0f * 8.0f : 0.f;  // pre-scale: multiplied by 1/8 below
-            st[kt].y += (x & 0x0000ff00u) ? -100.0f * 8.0f : 0.f;
-            st[kt].z += (x & 0x00ff0000u) ? -100.0f * 8.0f : 0.f;
-            st[kt].w += (x & 0xff000000u) ? -100.0f * 8.0f : 0.f;
-          }
-        }
-      }
-      if (!FULL && N < nt * 16) {  // keys beyond the window in the last tile
-        const int kt = nt - 1, k0 = kt * 16 + 4 * g;
-#pragma unroll
-        for (int t2 = 0; t2 < MAXT; ++t2)
-          if (t2 == kt) {
-            if (k0 + 0 >= N) st[t2].x = -INFINITY;
-            if (k0 + 1 >= N) st[t2].y = -INFINITY;
-            if (k0 + 2 >= N) st[t2].z = -INFINITY;
-            if (k0 + 3 >= N) st[t2].w = -INFINITY;
-          }
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < MAXT; ++kt)
-        if (FULL || kt < nt) mx = fmaxf(fmaxf(mx, fmaxf(st[kt].x, st[kt].y)), fmaxf(st[kt].z, st[kt].w));
-      mx = quad_max(mx);
-      const float mxs = mx * c_scale;
-      float sum = 0.f;
-      u32x2 pk[MAXT];  // packed bf16 probabilities, kept as dwords (bit-cast at the MFMA)
-#pragma unroll
-      for (int kt = 0; kt < MAXT; ++kt) {
-        if (FULL || kt < nt) {
-          const float e0 = __builtin_amdgcn_exp2f(fmaf(st[kt].x, c_scale, -mxs));
-          const float e1 = __builtin_amdgcn_exp2f(fmaf(st[kt].y, c_scale, -mxs));
-          const float e2 = __builtin_amdgcn_exp2f(fmaf(st[kt].z, c_scale, -mxs));
-          const float e3 = __builtin_amdgcn_exp2f(fmaf(st[kt].w, c_scale, -mxs));
-          sum += (e0 + e1) + (e2 + e3);
-          pk[kt] = u32x2{pack_bf16x2(e0, e1), pack_bf16x2(e2, e3)};
-        } else {
-          pk[kt] = u32x2{0u, 0u};
-        }
-      }
-      sum = quad_sum(sum);
-      const float inv = __builtin_amdgcn_rcpf(sum);
-
-      // ---- O^T = V^T P^T, 4 d-tiles of 16 ----
-      auto pv = [&](int dt) -> u32x2 {
-        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < MAXT; ++kt) {
-          if (FULL || kt < nt) {
-            const bf16x4_t vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) bf16x4_t*)(s_v + kt * 2048 + voff[dt]));
-            o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, __builtin_bit_cast(bf16x4_t, pk[kt]), o, 0, 0, 0);
-          }
-        }
-        return u32x2{pack_bf16x2(o.x * inv, o.y * inv), pack_bf16x2(o.z * inv, o.w * inv)};
-      };
-      const bool live = tq >= 0 && tq < p.L_out;
-      if constexpr (WIDE) {
-        const bool odd = (g & 1) != 0;
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const u32x4 v = pair_rows(pv(2 * a), pv(2 * a + 1));
-          const int col = col_q + 32 * a + (odd ? 16 + 4 * (g - 1) : 4 * g);
-          if (live) *reinterpret_cast<u32x4*>(out + (int64_t)tq * p.D + col) = v;
-        }
-      } else {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const u32x2 packed = pv(dt);
-          if (live) *reinterpret_cast<u32x2*>(out + (int64_t)tq * p.D + col_q + dt * 16 + 4 * g) = packed;
-        }
-      }
-    }
-
-    if (!has_next) break;
-    __syncthreads();               // every wave is done with this item's K / V image and tables
-    stage(item + G, slot ^ 1, kreg, vreg);
-    if (has_nn) put_tab(slot, tv_nn, gv_nn);   // the item after next replaces the finished one
-    masked = __syncthreads_or(differs(slot ^ 1)) != 0;
-    slot ^= 1;
-    item += G;
-    has_next = has_nn;
   }
 }
 
@@ -670,36 +396,18 @@ extern "C" int aurora_hip_window_attention(const void* qkv, const float* qkv_bia
   AURORA_CHECK_ARG(blocks < ((int64_t)1 << 31), "window_attention: grid too large");
   AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens, L_out};
   if (dtype == AURORA_BF16) {
-    static const int variant = [] { const char* e = getenv("AURORA_ATTN_VARIANT"); return e ? atoi(e) : 4; }();
-    if (variant == 0 || variant == 3 || variant == 4) {   // one workgroup per (window, head); 3: 16-byte result stores; 4: whole rows
-      if (win_tokens != MAXN)
-        hipLaunchKernelGGL((window_attention_bf16<false, 1>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
-      else if (variant == 0)
-        hipLaunchKernelGGL((window_attention_bf16<true, 0>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
-      else if (variant == 3)
-        hipLaunchKernelGGL((window_attention_bf16<true, 1>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
-      else
-        hipLaunchKernelGGL((window_attention_bf16<true, 2>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
-    } else {
-      // persistent: 4 workgroups per CU (LDS-limited), grid-stride over the (batch, window, head) items
-      const int64_t resident = (int64_t)device_cus() * 4;
-      const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
-      const int total = (int)blocks;
-      if (win_tokens == MAXN) {
-        if (variant == 1)
-          hipLaunchKernelGGL((window_attention_bf16_pipe<true, false>), dim3(grid), dim3(192), 0, as_stream(stream), p, total);
-        else
-          hipLaunchKernelGGL((window_attention_bf16_pipe<true, true>), dim3(grid), dim3(192), 0, as_stream(stream), p, total);
-      } else {
-        hipLaunchKernelGGL((window_attention_bf16_pipe<false, true>), dim3(grid), dim3(192), 0, as_stream(stream), p, total);
-      }
-    }
+    // one workgroup per (window, head); full 144-token windows store whole 128-byte rows
+    if (win_tokens != MAXN)
+      hipLaunchKernelGGL((window_attention_bf16<false, 1>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
+    else
+      hipLaunchKernelGGL((window_attention_bf16<true, 2>), dim3((unsigned)blocks), dim3(192), 0, as_stream(stream), p);
   } else {
     const size_t lds = 2 * MAXN * HD * 4 + MAXN * 4 + MAXN + 16;
-    static bool attr = false;
-    if (!attr) {
+    static bool attr_done_dev[64] = {false};   // function attributes are per device
+    bool& attr_done = attr_done_dev[current_device() & 63];
+    if (!attr_done) {
       (void)hipFuncSetAttribute((const void*)window_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = true;
+      attr_done = true;
     }
     hipLaunchKernelGGL(window_attention_f32, dim3((unsigned)blocks), dim3(192), lds, as_stream(stream), p);
   }

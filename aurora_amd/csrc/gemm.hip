@@ -806,237 +806,6 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearA
 }
 
 constexpr int MID_LDS = 3 * (BM2 + 128) * ROW2;   // 256 x 128 tiles: three stages of 24 KiB, two workgroups per CU
-constexpr int PERSIST_LDS = NSTAGE2 * STAGE2 + 8 * 2048 + 2 * 2048;   // ring | result transpose (2 KiB per wave) | bias x 2
-
-// PP: the main loop in ping-pong form (linear_kernel_256pp above: waves 4-7 one phase behind waves 0-3, one fragment set).
-template <int PRIO, int PP>
-__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256p(const LinearArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  if constexpr (PRIO != 0) {
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-  }
-  const int i16 = lane & 15, g = lane >> 4;
-  int off_x[8], off_w[4];
-#pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    const int row = wm * 128 + 16 * f + i16;
-    off_x[f] = row * ROW2 + ((g ^ swz2_x(row)) << 4);
-  }
-#pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    const int row = wn * 64 + 16 * (i16 >> 2) + 4 * f + (i16 & 3);
-    off_w[f] = OPER2 + row * ROW2 + ((g ^ swz2_w(row)) << 4);
-  }
-  const uint32_t n_tiles = (uint32_t)p.n_blocks, tiles_n = (uint32_t)p.tiles_n, tiles_m = n_tiles / tiles_n;
-  const int nt = p.k_tiles;   // >= 8 (dispatch), even
-
-  const char* src_x[2];
-  const char* src_w[2];
-  int64_t m0 = 0;
-  int n0 = 0;
-  // (`opaque`: per-lane constants of the tile loop -- staging rows, swizzles, epilogue offsets -- are recomputed per tile;
-  // hoisted out of the loop they would be spilled, and a spill RELOAD is a vector-memory operation whose wait drains
-  // the LDS-DMA queue, i.e. the very prologue the epilogue is supposed to run under)
-  auto lane_now = []() {   // the lane id, rematerialised (asm volatile is neither hoisted nor merged)
-    int l;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    return l;
-  };
-  auto locate = [&](uint32_t tile) {
-    uint32_t tile_m, tile_n;
-    tile_of_block(tile, n_tiles, tiles_m, tiles_n, tile_m, tile_n);
-    m0 = (int64_t)tile_m * BM2;
-    n0 = (int)tile_n * BN2;
-    const int tid_l = wave * 64 + lane_now();
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int id = r * THREADS2 + tid_l;
-      const int row = id >> 2, c = id & 3;
-      int64_t gm = m0 + row;
-      gm = gm < p.M ? gm : p.M - 1;
-      src_x[r] = p.A + gm * p.lda_b + ((c ^ swz2_x(row)) << 4);
-      src_w[r] = p.W + (int64_t)(n0 + row) * p.ldw_b + ((c ^ swz2_w(row)) << 4);
-    }
-  };
-  auto stage = [&](int kt) {
-    const int64_t koff = (int64_t)kt * ROW2;
-    char* base = smem + (kt & (NSTAGE2 - 1)) * STAGE2;
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[r] + koff),
-                                       (lds_ptr_t)(base + (r * THREADS2 + wave * 64) * 16), 16, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
-                                       (lds_ptr_t)(base + OPER2 + (r * THREADS2 + wave * 64) * 16), 16, 0, 0);
-  };
-
-  f32x4 acc[4][8];  // [fn][fm]
-  auto read_frags = [&](int kt, u32x4 (&fw)[4], u32x4 (&fx)[8]) {
-    const char* buf = smem + (kt & (NSTAGE2 - 1)) * STAGE2;
-#pragma unroll
-    for (int f = 0; f < 4; ++f) fw[f] = *reinterpret_cast<const u32x4*>(buf + off_w[f]);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) fx[f] = *reinterpret_cast<const u32x4*>(buf + off_x[f]);
-  };
-  auto mma_rows = [&](u32x4 (&cw)[4], u32x4 (&cx)[8], int fm_lo, int fm_hi) {
-#pragma unroll
-    for (int fm = fm_lo; fm < fm_hi; ++fm)
-#pragma unroll
-      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = Mma<bf16_t>::run(cw[fn], cx[fm], acc[fn][fm]);
-  };
-  bool stores_pending = false;   // 16 result stores of the previous tile sit behind this tile's prologue in the queue
-  auto step = [&](int kt, u32x4 (&cw)[4], u32x4 (&cx)[8], u32x4 (&nw)[4], u32x4 (&nx)[8]) {
-    mma_rows(cw, cx, 0, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    // my pieces of stage kt+1 have landed once only the younger operations remain outstanding
-    if (kt < 3 && stores_pending) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // 2 stages + 16 stores
-    else if (kt + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (kt + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // RAW: stage kt+1 complete.  WAR: everyone has read stage kt.
-    asm volatile("" ::: "memory");
-    if (kt + NSTAGE2 < nt) stage(kt + NSTAGE2);  // into stage kt's buffer
-    read_frags(kt + 1, nw, nx);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_rows(cw, cx, 2, 8);
-  };
-
-  // A tile's prologue: its bias slice first (one 4-byte LDS-DMA per lane: 64 features per wave, oldest in the queue, so
-  // it has landed whenever stage 0 has), then the first four K-stages.
-  char* const s_bias = smem + NSTAGE2 * STAGE2 + 8 * 2048;   // [2][8 waves][64 floats]
-  int parity = 0;
-  auto prologue = [&](int par) {
-    if (p.bias)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + n0 + wn * 64 + lane_now()),
-                                       (lds_ptr_t)(s_bias + par * 2048 + wave * 256), 4, 0, 0);
-    stage(0);
-    stage(1);
-    stage(2);
-    stage(3);
-  };
-  uint32_t tile = blockIdx.x;
-  locate(tile);
-  prologue(0);
-  for (;;) {
-    const int64_t cm0 = m0;   // this tile (locate() moves m0 / n0 on to the next one before the epilogue)
-    const int cn0 = n0;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (stores_pending) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");   // stage 0 landed: 3 stages + 16 stores younger
-    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if constexpr (PP == 0) {
-      u32x4 fwA[4], fxA[8], fwB[4], fxB[8];
-      read_frags(0, fwA, fxA);
-      for (int kt = 0; kt + 2 < nt; kt += 2) {
-        step(kt, fwA, fxA, fwB, fxB);
-        step(kt + 1, fwB, fxB, fwA, fxA);
-      }
-      step(nt - 2, fwA, fxA, fwB, fxB);  // fetches the last stage; its wait is vmcnt(0)
-      mma_rows(fwB, fxB, 0, 8);
-    } else {
-      if (wm == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
-      for (int s_ = 0; s_ < nt; ++s_) {
-        u32x4 fw[4], fx[8];
-        read_frags(s_, fw, fx);                                   // L(s): fragments of stage s ...
-        if (s_ >= 1 && s_ + 3 < nt) stage(s_ + 3);                // ... refill the buffer of stage s-1 ...
-        // ... and settle my pieces of stage s+1 (stages s+2, s+3 are younger; so are the previous tile's 16 stores
-        // until the first in-loop stage, issued behind them, is the one waited for)
-        if (s_ < 3 && stores_pending) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (s_ + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (s_ + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        mma_rows(fw, fx, 0, 8);                                   // M(s): the matrix pipe is this wave's alone
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-    }
-
-    // ---- next tile's prologue, then this tile's epilogue ----
-    const uint32_t next = tile + gridDim.x;
-    const bool has_next = next < n_tiles;
-    // every wave has read the last stage: the ring is free (ping-pong: the early half waits for the late half)
-    if (PP == 0 || wm == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (has_next) {
-      locate(next);
-      prologue(parity ^ 1);
-    }
-    const bool full_rows = cm0 + BM2 <= p.M;
-    const int lane_l = lane_now();
-    const int i16 = lane_l & 15, g = lane_l >> 4;   // (shadow the loop-invariant copies)
-    float bias_v[16];   // this lane's 16 output features, out of this tile's LDS slice
-    {
-      const f32x4* bs = reinterpret_cast<const f32x4*>(s_bias + parity * 2048 + wave * 256 + g * 64);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = p.bias ? bs[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-        bias_v[4 * q] = bv.x; bias_v[4 * q + 1] = bv.y; bias_v[4 * q + 2] = bv.z; bias_v[4 * q + 3] = bv.w;
-      }
-    }
-    parity ^= 1;
-    char* mine = smem + NSTAGE2 * STAGE2 + wave * 2048;
-    const int rr = lane_l >> 3, cc = lane_l & 7;
-    bf16_t* cbase = reinterpret_cast<bf16_t*>(p.C) + cn0 + wn * 64 + cc * 8;
-#pragma unroll
-    for (int part = 0; part < 8; ++part) {   // 16 rows (one fragment row) per pass through the wave's 2 KiB
-      {
-        const int fm = part;
-        float v[16];
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) {
-          v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
-          v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
-          v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
-          v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
-        }
-        if (p.act == AURORA_ACT_GELU) {
-#pragma unroll
-          for (int t = 0; t < 16; t += 2) {
-            const f32x2_hw r = gelu_sig2(f32x2_hw{v[t], v[t + 1]});
-            v[t] = r.x;
-            v[t + 1] = r.y;
-          }
-        } else if (p.act == AURORA_ACT_SILU) {
-#pragma unroll
-          for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
-        }
-        const int row = i16, sw = row & 7;
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-          *reinterpret_cast<u32x4*>(mine + row * 128 + (((2 * g + q) ^ sw) << 4)) =
-              u32x4{pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
-                    pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7])};
-      }
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = it * 8 + rr;
-        const u32x4 d = *reinterpret_cast<const u32x4*>(mine + row * 128 + ((cc ^ rr) << 4));
-        const int64_t m = cm0 + wm * 128 + part * 16 + row;
-        if (full_rows) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
-        else if (m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
-      }
-    }
-    if (!has_next) break;
-    if (!full_rows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // unknown number of stores: drain
-    stores_pending = full_rows;
-    tile = next;
-  }
-}
-
 
 // =================================================================================================
 // fp32 linear layers on the bf16 matrix pipe: "3 x bf16" operand splitting.
@@ -1580,7 +1349,6 @@ struct LinearLnArgs {
   const float* bias; const float* gain; const float* shift;
   const float* x_in; int64_t ldx; float* x_out; int64_t ldo; bf16_t* xb; int64_t ldb;
   int64_t M; int k_tiles; float eps;
-  int stagger;   // first-round workgroups on every other CU start this many s_sleep(127) periods (~4 us each) late
 };
 
 __device__ __forceinline__ float group4_sum(float v) {   // over the 4 lane groups (lanes l, l^16, l^32, l^48)
@@ -1601,8 +1369,6 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
   // All tiles cost the same, so the CUs of a launch run in lockstep: every main loop at once (HBM idle), then every
   // epilogue at once (768 KiB per tile against a 256th of the memory system).  Delaying the first-round workgroups of
   // every other CU by half a tile puts one half's epilogues under the other half's main loops for the whole launch.
-  if (p.stagger > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1))
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
   const char* src_x;
   const char* src_w[4];
@@ -1848,7 +1614,7 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
   // (fp32 in split mode: the kernel choice must not depend on M, or a latitude band of a sharded model
   // would round differently from the same rows of the un-sharded one.)
   const bool split = dtype == AURORA_F32 && mode >= 1;
-  bool big = (M >= 1024 || split) && N % BN2 == 0 && getenv("AURORA_GEMM_SMALL_ONLY") == nullptr;
+  bool big = (M >= 1024 || split) && N % BN2 == 0;
   bool mid = false;   // bf16 only: 256 x 128 tiles of the ring kernel, two 4-wave workgroups per CU
   if (big && !split) {
     // Few tiles (a latitude band of a sharded model, the coarse stages): 256 x 256 tiles leave CUs idle or end in a
@@ -1861,7 +1627,6 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
     const int64_t cus = device_cus();
     const int64_t nb_big = ((M + BM2 - 1) / BM2) * (N / BN2), nb_small = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const int64_t nb_mid = ((M + BM2 - 1) / BM2) * (N / 128);
-    static const int force = [] { const char* e = getenv("AURORA_GEMM_TILE"); return !e ? 0 : e[0] == 'b' ? 1 : e[0] == 'm' ? 2 : 3; }();
     if (dtype == AURORA_BF16) {
       auto cost = [&](int64_t nb, int64_t slots, double a, double b) {
         const int64_t full = nb / slots, rem = nb % slots;
@@ -1870,11 +1635,11 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
       };
       const double t_big = cost(nb_big, cus, 10.1, 0.0266), t_mid = cost(nb_mid, 2 * cus, 7.7, 0.0317),
                    t_small = cost(nb_small, 2 * cus, 7.6, 0.0153);
-      if (force == 2 || (force == 0 && t_mid < 0.97 * t_big && t_mid <= t_small)) mid = true;
-      else if (force == 3 || (force == 0 && t_small < 0.97 * t_big)) big = false;
+      if (t_mid < 0.97 * t_big && t_mid <= t_small) mid = true;
+      else if (t_small < 0.97 * t_big) big = false;
     } else {
       auto fill = [&](int64_t nb, int64_t slots) { return (double)nb / (double)(((nb + slots - 1) / slots) * slots); };
-      if (force == 3 || (force == 0 && 0.8 * fill(nb_small, 2 * cus) > fill(nb_big, cus))) big = false;
+      if (0.8 * fill(nb_small, 2 * cus) > fill(nb_big, cus)) big = false;
     }
   }
   const int bm = big ? BM2 : BM, bn = mid ? 128 : big ? BN2 : BN, rowb = big ? ROW2 : ROW_BYTES;
@@ -1905,13 +1670,8 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
     (void)hipFuncSetAttribute((const void*)linear_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<float, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 2, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256p<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PERSIST_LDS);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
@@ -1919,10 +1679,8 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
     (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
     attr_done = true;
   }
-  // two fp16 terms: the ping-pong kernel (128 x 256 tiles, K-stages of 32) when K allows; AURORA_F32_VARIANT=0 keeps the
-  // in-phase 256 x 256 kernel for A/B
-  static const int f32_variant = [] { const char* e = getenv("AURORA_F32_VARIANT"); return e ? atoi(e) : 1; }();
-  const bool f32pp = big && split && mode == 2 && (f32_variant == 1 || pre) && K % 32 == 0 && K >= 96;
+  // two fp16 terms: the ping-pong kernel (128 x 256 tiles, K-stages of 32) when K allows, else the in-phase 256 x 256 one
+  const bool f32pp = big && split && mode == 2 && K % 32 == 0 && K >= 96;
   auto launch_f32pp = [&]() {
     LinearArgs q = p;
     q.k_tiles = K / 32;
@@ -1952,38 +1710,10 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
       hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (dtype == AURORA_F32)
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-    else {
-      static const int variant = [] { const char* e = getenv("AURORA_GEMM_VARIANT"); return e ? atoi(e) : 5; }();
-      // AURORA_GEMM_VARIANT (A/B switch, profiles/r02_ab_gemm_variants.log):
-      //   5 (default) ping-pong main loop, one workgroup per tile
-      //   8 ping-pong; persistent form of it where that wins IN ISOLATION (N >= 1024 and K <= 2048: +3..8 % when one launch
-      //     is repeated on cache-resident operands; the long-K / two-n-tile shapes lose 1-2 % to it).  Inside the forecast
-      //     step the persistent form is 0.4 ms per step SLOWER than 5 (profiles/r02_ab_variants_instep.log: 74.94 vs 74.58 ms
-      //     of bf16 GEMM, twice): its static tile-to-CU assignment cannot absorb the uneven tile times of cold operands,
-      //     which the hardware dispatcher does for free -- so it is not the default
-      //   7 ping-pong, persistent wherever legal
-      //   4 in-phase ring kernel + static wave priority, persistent by the same shape rule (round 2's first default)
-      //   3 / 2 in-phase, persistent wherever legal, with / without priority      1 / 0 in-phase ring kernel with / without
-      const bool plain = C2 == nullptr && residual == nullptr && vec && N % BN2 == 0 && p.k_tiles >= 8;
-      const bool wins = N >= 1024 && K <= 2048;
-      const bool many = p.n_blocks > device_cus();
-      const dim3 pgrid((unsigned)device_cus());   // persistent kernels: one workgroup per CU walks over the tiles
-      if (variant >= 7 && plain && many && (variant == 7 || wins))
-        hipLaunchKernelGGL((linear_kernel_256p<0, 1>), pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
-      else if ((variant >= 7 || variant == 5) && p.k_tiles >= 4)
-        hipLaunchKernelGGL(linear_kernel_256pp<0>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-      else if (variant == 6 && p.k_tiles >= 4)
-        hipLaunchKernelGGL(linear_kernel_256pp<1>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-      else if (variant >= 2 && variant <= 4 && plain && many && (variant != 4 || wins)) {
-        if (variant == 2)
-          hipLaunchKernelGGL((linear_kernel_256p<0, 0>), pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
-        else
-          hipLaunchKernelGGL((linear_kernel_256p<1, 0>), pgrid, dim3(THREADS2), PERSIST_LDS, as_stream(stream), p);
-      } else if (variant == 1 || variant == 3 || variant == 4)
-        hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4, 1>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-      else
-        hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-    }
+    else if (p.k_tiles >= 4)   // ping-pong main loop, one workgroup per tile
+      hipLaunchKernelGGL(linear_kernel_256pp<0>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
+    else
+      hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
   } else {
     if (dtype == AURORA_F32)
       hipLaunchKernelGGL(linear_kernel<float>, grid, dim3(THREADS), 4 * TILE_BYTES, as_stream(stream), p);
@@ -2019,11 +1749,7 @@ extern "C" int aurora_hip_linear_layernorm(const void* A, int64_t lda, const voi
   AURORA_CHECK_ARG((!bias || ((uintptr_t)bias % 16) == 0) && (!gain || ((uintptr_t)gain % 16) == 0) &&
                        (!shift || ((uintptr_t)shift % 16) == 0), "linear_layernorm: unaligned bias / gain / shift");
   LinearLnArgs p{(const char*)A, lda * 2, (const char*)W, ldw * 2, bias, gain, shift, x_in, ldx, x_out, ldo, (bf16_t*)x_bf16, ldb,
-                 M, K / 32, eps, 0};
-  {
-    static const int stagger = [] { const char* e = getenv("AURORA_FUSED_STAGGER"); return e ? atoi(e) : 0; }();
-    p.stagger = stagger;
-  }
+                 M, K / 32, eps};
   static bool attr_done_dev[64] = {false};
   bool& attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {

@@ -485,7 +485,7 @@ Resampler pack_resampler(Model& m, const std::string& prefix, int depth, int hea
       w_max = std::max(w_max, absmax_of(p + nm));
     const float ln_bound = absmax_of(p + ".2.weight") * sqrtf((float)l.dim) + absmax_of(p + ".2.bias");
     l.f16_mode = (w_max < 1000.f && ln_bound < F16_SAFE) ? bounded_mode() : -1;
-    if (l.f16_mode == 2 && getenv("AURORA_NO_PRESPLIT") == nullptr) {
+    if (l.f16_mode == 2) {
       auto presplit = [&](const std::string& name) -> const void* {
         const Tensor& t = m.T_(name);
         const int64_t N = t.shape[0], K = t.shape[1];
@@ -542,8 +542,12 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
         L.linear(A, lda, Ws, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0,
                  2 | AURORA_F32_W_SPLIT | (a_pairs ? AURORA_F32_A_SPLIT : 0), ctx_max, limit);
         L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, 1, ctx_max, limit);
+      } else if (ly.f16_mode == 2) {   // one guarded call: the device word picks the two- or the three-term kernel
+        L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, 2, ctx_max, limit);
       } else {
-        L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, ly.f16_mode, ctx_max, limit);
+        // a pinned mode (AURORA_F32_GEMM) or weights outside the two-term range: NO guard -- a mode-1 launch that carries a
+        // guard is the three-term half of a guarded pair and runs only if the guard FAILS (include/aurora_hip.h)
+        L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, ly.f16_mode, nullptr, 0.f);
       }
     };
     // |ctx| <= g_a * word + g_c < F16_SAFE  <=>  word < (F16_SAFE - g_c) / g_a; a context in pairs comes with its own limit
@@ -731,7 +735,7 @@ const float* embed_weight(Model& m, int kind, int T, int& K, int& Kpad) {
   DevBuf b = to_device(host);
   m.embed_l1[key] = l1;
   // the fp16-pair form for the guarded two-term kernel (the raw, normalised inputs are bounded only by the guard)
-  if (bounded_mode() == 2 && getenv("AURORA_NO_PRESPLIT") == nullptr && wmax < 1000.f && m.D % 256 == 0 && Kpad >= 96) {
+  if (bounded_mode() == 2 && wmax < 1000.f && m.D % 256 == 0 && Kpad >= 96) {
     DevBuf sp((size_t)m.D * Kpad * 4);
     if (aurora_hip_split_f16(b.f(), Kpad, sp.p, Kpad, m.D, Kpad, 64.0f, nullptr) != AURORA_OK)
       throw std::runtime_error(aurora_hip_last_error());
@@ -1252,7 +1256,7 @@ extern "C" int aurora_hip_finalize(aurora_hip_model* mp, void* stream) {
       m.surf_b0 = amax(host_of("encoder.surf_mlp.net.0.bias"));
       m.surf_c = amax(host_of("encoder.surf_token_embeds.bias")) + amax(host_of("encoder.surf_level_encoding"));
       auto eligible = [](int64_t N, int64_t K) { return N % 256 == 0 && K % 32 == 0 && K >= 96; };
-      m.surf_chain = bounded_mode() == 2 && getenv("AURORA_NO_PRESPLIT") == nullptr && amax(w0) < 1000.f && amax(w2) < 1000.f &&
+      m.surf_chain = bounded_mode() == 2 && amax(w0) < 1000.f && amax(w2) < 1000.f &&
                      eligible(N0, K0) && eligible(K0, N0);
       m.surf_w0_s = DevBuf();
       m.surf_w2_s = DevBuf();

@@ -46,52 +46,6 @@ struct LnArgs {
   int split_res; // fp32 kernel: the residual rows are in that layout (value = high half + remainder)
 };
 
-template <typename T, int MAXC>
-__global__ __launch_bounds__(256) void layernorm_kernel(const LnArgs p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= p.M) return;
-  const int n_pieces = p.D >> 3;
-  const T* yr = reinterpret_cast<const T*>(p.y) + row * p.ldy;
-  float v[MAXC][8];
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i)
-    if (lane + 64 * i < n_pieces) load8(yr + (lane + 64 * i) * 8, v[i]);
-  float mean, rstd;
-  row_stats<MAXC>(v, lane, n_pieces, 1.0f / p.D, p.eps, mean, rstd);
-
-  const float* rr = nullptr;
-  if (p.res) rr = p.res + (p.res_mod > 0 ? row % p.res_mod : row) * p.ldr;
-#pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
-    const int e = (lane + 64 * i) * 8;
-    if (lane + 64 * i < n_pieces) {
-      float gn[8], sh[8], o[8];
-      if (p.gain) load8(p.gain + e, gn);
-      if (p.shift) load8(p.shift + e, sh);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float t = (v[i][j] - mean) * rstd;
-        if (p.gain) t *= gn[j];
-        if (p.shift) t += sh[j];
-        o[j] = t;
-      }
-      if (rr) {
-        float r8[8];
-        load8(rr + e, r8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] += r8[j];
-      }
-      if (p.out_f32) store8(p.out_f32 + row * p.ldo + e, o);
-      if (p.out_t) store8(reinterpret_cast<T*>(p.out_t) + row * p.ldt + e, o);
-    }
-  }
-}
-
-// fp32 rows: 16-byte pieces (4 features) per lane and chunk, lanes on consecutive pieces -- every load / store
-// instruction of a wave covers 1 KiB contiguous.  (The generic kernel above gives a lane 8 consecutive features,
-// 32 bytes for fp32, so each of its two 16-byte accesses touches every line of the row only half: measured
-// 3.0 TB/s on the 842400 x 512 decoder LayerNorms against 6.4 TB/s for the bf16-input ones.)
 template <typename T, int NC>   // chunks of 256 features
 __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
   const int lane = threadIdx.x & 63;
@@ -324,20 +278,14 @@ static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const f
     else if (D <= 2048) hipLaunchKernelGGL((layernorm_f32_kernel<float, 8>), grid, block, 0, as_stream(stream), p);
     else hipLaunchKernelGGL((layernorm_f32_kernel<float, 16>), grid, block, 0, as_stream(stream), p);
   } else {
-    // bf16 rows go through the 4-features-per-lane kernel as well: every access of a wave covers whole cache lines (8-byte
-    // bf16 pieces, 16-byte fp32 pieces on consecutive lanes), where the 8-features-per-lane kernel reads and writes the
-    // fp32 residual stream in two interleaved halves.  18.07 -> 17.43 ms of LayerNorm per step in the same run
-    // (profiles/r02_ab_ln_layout.log); AURORA_LN_VARIANT=0 selects the old kernel.
-    static const int variant = [] { const char* e = getenv("AURORA_LN_VARIANT"); return e ? atoi(e) : 1; }();
-    if (variant == 1 && D % 4 == 0 && D <= 2048) {
-      const dim3 grid(row_blocks(M)), block(256);
-      if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 1>), grid, block, 0, as_stream(stream), p);
-      else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 2>), grid, block, 0, as_stream(stream), p);
-      else if (D <= 1024) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 4>), grid, block, 0, as_stream(stream), p);
-      else hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 8>), grid, block, 0, as_stream(stream), p);
-      return check_launch("layernorm");
-    }
-    AURORA_DISPATCH_ROW(layernorm_kernel, bf16_t, D, dim3(row_blocks(M)), dim3(256), 0, as_stream(stream), p);
+    // bf16 rows go through the same 4-features-per-lane kernel: every access of a wave covers whole cache lines (8-byte
+    // bf16 pieces, 16-byte fp32 pieces on consecutive lanes; profiles/r02_ab_ln_layout.log)
+    const dim3 grid(row_blocks(M)), block(256);
+    if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 1>), grid, block, 0, as_stream(stream), p);
+    else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 2>), grid, block, 0, as_stream(stream), p);
+    else if (D <= 1024) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 4>), grid, block, 0, as_stream(stream), p);
+    else if (D <= 2048) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 8>), grid, block, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 16>), grid, block, 0, as_stream(stream), p);
   }
   return check_launch("layernorm");
 }

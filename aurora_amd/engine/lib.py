@@ -272,7 +272,7 @@ F32_A_SPLIT, F32_W_SPLIT, F32_C_SPLIT = 4, 8, 16   # include/aurora_hip.h: opera
 def two_term_free() -> bool:
     """True unless the user pinned an fp32 GEMM mode (AURORA_F32_GEMM or an enclosing `f32_gemm`) -- the condition under
     which `bounded_activations` switches to the two-term split, and so the one for handing it pre-split operands."""
-    return _f32_state()[0] < 0 and os.environ.get("AURORA_F32_GEMM") is None and os.environ.get("AURORA_NO_PRESPLIT") is None
+    return _f32_state()[0] < 0 and os.environ.get("AURORA_F32_GEMM") is None
 
 
 def presplit_ok(n: int, k: int) -> bool:
