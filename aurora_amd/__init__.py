@@ -16,7 +16,7 @@ from aurora_amd.model.aurora import (
     AuroraSmallPretrained,
     AuroraWave,
 )
-from aurora_amd.rollout import rollout
+from aurora_amd.rollout import rollout, write_rollout
 
 
 class Tracker:
@@ -44,5 +44,6 @@ __all__ = [
     "Batch",
     "Metadata",
     "rollout",
+    "write_rollout",
     "Tracker",
 ]

@@ -170,12 +170,7 @@ class Batch:
             md,
         )
 
-    def to_netcdf(self, path: str | Path) -> None:
-        try:
-            import xarray as xr
-        except ImportError as e:
-            raise RuntimeError("`xarray` must be installed.") from e
-
+    def _netcdf_payload(self):
         arr = lambda x: x.detach().cpu().numpy()  # noqa: E731
         data = {}
         for k, v in self.surf_vars.items():
@@ -191,32 +186,50 @@ class Batch:
             "level": list(self.metadata.atmos_levels),
             "rollout_step": self.metadata.rollout_step,
         }
-        xr.Dataset(data, coords=coords).to_netcdf(path)
+        return data, coords
+
+    def to_netcdf(self, path: str | Path) -> None:
+        """Write the batch to a file (reference batch.py:224-257): through `xarray` when installed, else through
+        SciPy's netCDF-3 writer with the same variables, dimensions and coordinates (aurora_amd/netcdf.py)."""
+        from aurora_amd import netcdf
+
+        data, coords = self._netcdf_payload()
+        netcdf.write_dataset(path, data, coords)
 
     @classmethod
-    def from_netcdf(cls, path: str | Path) -> "Batch":
-        try:
-            import xarray as xr
-        except ImportError as e:
-            raise RuntimeError("`xarray` must be installed.") from e
+    def from_netcdf(cls, path) -> "Batch":
+        """Load a batch from a file -- or from the per-rank files of a sharded forecast (`BandBatch.to_netcdf`): a
+        list of paths, or the `{rank}` template they were written with; the latitude bands are joined north to south."""
+        from aurora_amd import netcdf
 
-        ds = xr.load_dataset(path, engine="netcdf4")
+        if isinstance(path, (list, tuple)):
+            paths = [Path(p) for p in path]
+        elif "{rank" in str(path):
+            paths = netcdf.band_paths(path)
+            if not paths:
+                raise FileNotFoundError(f"no files match {path}")
+        else:
+            paths = [Path(path)]
+        parts = [netcdf.read_dataset(p) for p in paths]
+        parts.sort(key=lambda part: -float(part[1]["latitude"][0]))   # latitudes decrease: northernmost band first
+        coords = parts[0][1]
+        lat = np.concatenate([p_[1]["latitude"] for p_ in parts])
         groups: dict[str, dict[str, torch.Tensor]] = {"surf_": {}, "static_": {}, "atmos_": {}}
-        for key in ds:
+        for key in parts[0][0]:
             for prefix, dst in groups.items():
                 if key.startswith(prefix):
-                    dst[key[len(prefix) :]] = torch.from_numpy(ds[key].values)
+                    dst[key[len(prefix):]] = torch.from_numpy(np.concatenate([p_[0][key] for p_ in parts], axis=-2))
                     break
         return cls(
             groups["surf_"],
             groups["static_"],
             groups["atmos_"],
             Metadata(
-                lat=torch.from_numpy(ds.latitude.values),
-                lon=torch.from_numpy(ds.longitude.values),
-                time=tuple(ds.time.values.astype("datetime64[s]").tolist()),
-                atmos_levels=tuple(ds.level.values),
-                rollout_step=int(ds.rollout_step.values),
+                lat=torch.from_numpy(lat),
+                lon=torch.from_numpy(coords["longitude"]),
+                time=tuple(coords["time"]),
+                atmos_levels=tuple(coords["level"]),
+                rollout_step=int(coords["rollout_step"]),
             ),
         )
 
@@ -232,9 +245,27 @@ class BandBatch(Batch):
 
     full_patch_rows: int = 0
     band: tuple[int, int] = (0, 0)
+    rank: int = 0
+    world: int = 1
 
     def crop(self, patch_size: int) -> "BandBatch":
         return self  # a band is cut out of an already cropped grid
+
+    def to_netcdf(self, path: str | Path) -> None:
+        """Sharded output: every rank writes ITS latitude band to its own file -- `path` is a
+        template with a `{rank}` field, e.g. "step{rank:02d}.nc" -- and nothing is gathered.  Each file is a complete
+        dataset on its latitude slice (same variables / dimensions / coordinates as `Batch.to_netcdf`, plus the band
+        bookkeeping as global attributes), so `Batch.from_netcdf(template)` here, or
+        `xarray.open_mfdataset(files, combine="by_coords")` anywhere, reassembles the un-sharded fields."""
+        from aurora_amd import netcdf
+
+        if "{rank" not in str(path):
+            raise ValueError("a latitude band is written per rank: the path needs a `{rank}` field, e.g. 'pred.{rank}.nc'")
+        data, coords = self._netcdf_payload()
+        attrs = {"aurora_band_patch_rows": np.asarray(self.band, dtype=np.int32),
+                 "aurora_full_patch_rows": np.int32(self.full_patch_rows),
+                 "aurora_rank": np.int32(self.rank), "aurora_world": np.int32(self.world)}
+        netcdf.write_dataset(str(path).format(rank=self.rank), data, coords, attrs)
 
 
 def _interpolate(v, lat, lon, lat_new, lon_new) -> torch.Tensor:

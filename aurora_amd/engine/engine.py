@@ -565,7 +565,7 @@ class Engine:
                 cut = lambda d_: {k: v[..., h0 * P:h1 * P, :] for k, v in d_.items()}  # noqa: E731
                 batch = BandBatch(cut(batch.surf_vars), cut(batch.static_vars), cut(batch.atmos_vars),
                                   derive_metadata(md, lat=md.lat[h0 * P:h1 * P]), full_patch_rows=full_rows,
-                                  band=(h0, h1))
+                                  band=(h0, h1), rank=sh.rank, world=sh.world)
                 md = batch.metadata
             else:
                 assert band == (h0, h1), f"band {band} does not match this rank's rows {(h0, h1)}"
@@ -617,7 +617,7 @@ class Engine:
         cut = lambda d_: {k: v[..., h0 * P:h1 * P, :] for k, v in d_.items()}  # noqa: E731
         md = derive_metadata(batch.metadata, lat=batch.metadata.lat[h0 * P:h1 * P])
         return BandBatch(cut(batch.surf_vars), cut(batch.static_vars), cut(batch.atmos_vars), md,
-                         full_patch_rows=H // P, band=(h0, h1))
+                         full_patch_rows=H // P, band=(h0, h1), rank=sh.rank, world=sh.world)
 
     def _gather(self, pred: BandBatch, rows0, P: int) -> Batch:
         """Assemble the full fields on every rank: each rank broadcasts its band into place."""
@@ -1271,7 +1271,8 @@ class Engine:
                                  time=tuple(t + cfg.timestep for t in md.time), rollout_step=new_step)
         if self._cur_band is not None:
             return BandBatch(surf_out, dict(batch.static_vars), atmos_out, new_md,
-                             full_patch_rows=self._cur_band[0], band=self._cur_band[1])
+                             full_patch_rows=self._cur_band[0], band=self._cur_band[1], rank=self.shard.rank,
+                             world=self.shard.world)
         return Batch(surf_out, dict(batch.static_vars), atmos_out, new_md)
 
     def _diff_fields(self, d, name, diff, head_names, P2, lvl_stride, prev_vars, levels, is_atmos):

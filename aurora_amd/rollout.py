@@ -10,7 +10,7 @@ import torch
 
 from aurora_amd.batch import Batch
 
-__all__ = ["rollout"]
+__all__ = ["rollout", "write_rollout"]
 
 _RING = 8   # history states per ring chunk
 
@@ -152,3 +152,62 @@ def _rollout_graphed(model, batch: Batch, steps: int) -> Generator[Batch, None, 
             st = stepper.state
             state = dataclasses.replace(st, surf_vars={k: st.surf_vars[k] for k in pred.surf_vars})
             stepper = None
+
+
+def _fill(template: str, **known) -> str:
+    """`template.format(**known)` that leaves the fields it does not know (e.g. `{rank:02d}`) as they are."""
+    import string
+
+    out = []
+    for text, field, spec, conv in string.Formatter().parse(template):
+        out.append(text)
+        if field is None:
+            continue
+        if field in known:
+            out.append(format(known[field], spec or ""))
+        else:
+            out.append("{" + field + ("!" + conv if conv else "") + (":" + spec if spec else "") + "}")
+    return "".join(out)
+
+
+def write_rollout(model, batch: Batch, steps: int, path_template: str, graph: bool = False) -> list[str]:
+    """Roll out `steps` predictions and write each to `path_template` (fields `{step}`, and `{rank}` for a sharded model
+    that keeps its state distributed: every rank writes its own latitude band, nothing is gathered -- see
+    `BandBatch.to_netcdf`).  The output path of SURVEY.md section 8 f-4, built on `rollout(..., to_host=True)`: the
+    device -> pinned-host copy of step s runs on a side stream under step s+1, and the file of step s is written by a
+    background thread meanwhile, so neither transfer nor encoding holds the next step up.  Returns the paths written
+    by this process.  (The reference's pattern is `[p.to("cpu") for p in rollout(...)]` + `Batch.to_netcdf`,
+    docs/usage.md:136-141, aurora/batch.py:224-257.)"""
+    import queue
+    import threading
+
+    if "{step" not in path_template:
+        raise ValueError("the path template needs a `{step}` field")
+    todo: "queue.Queue" = queue.Queue(maxsize=2)
+    written, errors = [], []
+
+    def writer():
+        while True:
+            item = todo.get()
+            if item is None:
+                return
+            pred, path = item
+            try:
+                pred.to_netcdf(path)
+                written.append(_fill(path, rank=getattr(pred, "rank", 0)))
+            except Exception as e:  # noqa: BLE001  (re-raised in the caller's thread below)
+                errors.append(e)
+
+    th = threading.Thread(target=writer, daemon=True)
+    th.start()
+    try:
+        for pred in rollout(model, batch, steps, graph=graph, to_host=True):
+            if errors:
+                break
+            todo.put((pred, _fill(path_template, step=pred.metadata.rollout_step)))
+    finally:
+        todo.put(None)
+        th.join()
+    if errors:
+        raise errors[0]
+    return written

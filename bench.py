@@ -22,10 +22,13 @@ One JSON line on stdout (rank 0), with two extra objects:
                 with HIP events on the launch stream during the timed steps, vs the 2.5 PF dense peak;
                 `attention` holds the same for the HBM-bound window-attention kernel (bytes / time
                 vs 8 TB/s).
-  cpu_baseline  the CPU oracle (a port of the reference's algorithm) timed on this box's host
-                cores on the largest sub-grid that fits the time budget (>= 1/4 of the grid when the 1/16 grid
-                takes < 35 s), scaled to the full grid by token count; plus the real reference's full-grid timing
-                measured in the build container (profiles/r02_reference_cpu.json).
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/aurora_oracle.py) timed on this box's host
+                cores on the SAME workload: the full 720 x 1440 grid, the same seeded weights and Batch as the GPU step
+                (a 1/16 sub-grid is timed first as a fall-back should the full grid not finish in its budget); plus
+                the real reference's full-grid timing measured in the build container (profiles/r02_reference_cpu.json).
+  parity_full_grid   the outputs of that oracle run against the GPU step's, per variable mean|out-ref| / mean|ref|
+                (the metric of the reference's tests/test_model.py:45-61): the fp32 engine must stay below 1e-4, the
+                bf16 (autocast) engine below 5e-3 -- the bench exits non-zero otherwise.
 """
 from __future__ import annotations
 
@@ -89,60 +92,145 @@ def build_model(device):
     return model.eval()
 
 
-CPU_SAMPLES = ((180, 360, 16), (360, 720, 4), (720, 1440, 1))  # (H, W, full/sample tokens)
+def _tmp_dir() -> Path:
+    """Scratch for the weights / outputs handed between the GPU process and the CPU oracle worker."""
+    import tempfile
+
+    shm = Path("/dev/shm")
+    try:
+        if shm.is_dir() and os.access(shm, os.W_OK):
+            import shutil
+
+            if shutil.disk_usage(shm).free > 12 << 30:
+                return shm
+    except OSError:
+        pass
+    return Path(tempfile.gettempdir())
 
 
-def cpu_worker(budget_s: float, threads: int) -> None:
-    """Subprocess body: time the CPU oracle (fp32 port of the reference algorithm) on growing
-    sub-grids of the 0.25-degree workload until the time budget is used; print one JSON object."""
+def cpu_worker(budget_s: float, threads: int, weights: str, out_path: str, H: int, W: int) -> None:
+    """Subprocess body: the CPU oracle (fp32 port of the reference algorithm) on the bench workload -- the weights the
+    GPU step used (`weights`: a torch.save'd state_dict) and the same seeded Batch.  A 1/16 sub-grid first (fall-back
+    sample), then the full grid, whose outputs go to `out_path` for the parity check.  One JSON object per finished
+    sample on stdout; the last one wins."""
     import aurora_amd
     from aurora_amd import normalisation as nz
     from oracle import aurora_oracle as oracle
 
     torch.set_num_threads(threads)
     with torch.device("meta"):
-        meta = aurora_amd.AuroraPretrained(autocast=True)
-        cfg = meta.config
-        shapes = {k: tuple(v.shape) for k, v in meta.state_dict().items()}
-    # Timing does not depend on the weight values: constant fill (1.3 B parameters in about a second).
-    sd = {k: torch.full(shp, 0.01) for k, shp in shapes.items()}
+        cfg = aurora_amd.AuroraPretrained(autocast=True).config
+    sd = torch.load(weights, map_location="cpu", mmap=True, weights_only=True)
     t_start = time.perf_counter()
-    result = None
-    for (H, W, frac) in CPU_SAMPLES:
-        b = synthetic_batch(cfg, H, W, 1, "cpu")
+    Hc = H - H % cfg.patch_size
+    samples = [(Hc // 4 - (Hc // 4) % cfg.patch_size, W // 4 - (W // 4) % cfg.patch_size, False), (H, W, True)]
+    for (h, w, full) in samples:
+        if h < cfg.patch_size or w < cfg.patch_size or (not full and (h, w) == (Hc, W)):
+            continue
+        b = synthetic_batch(cfg, h, w, 1, "cpu")
         t0 = time.perf_counter()
         with torch.inference_mode():
-            oracle.forward(sd, cfg, b.surf_vars, b.static_vars, b.atmos_vars, b.metadata.lat, b.metadata.lon,
-                           b.metadata.time, LEVELS, 0, nz.locations, nz.scales)
+            o_s, o_a, _ = oracle.forward(sd, cfg, b.surf_vars, b.static_vars, b.atmos_vars, b.metadata.lat,
+                                         b.metadata.lon, b.metadata.time, LEVELS, 0, nz.locations, nz.scales)
         dt = time.perf_counter() - t0
-        result = {"value": 1.0 / (dt * frac), "unit": "forecast-steps/s", "cores": threads, "kind": "port",
-                  "sample": f"CPU oracle (fp32 port of the reference forward, 1.3B-parameter model) on a {H}x{W} "
-                            f"sub-grid = 1/{frac:g} of the 720x1440 tokens in {dt:.2f} s; value = that rate / {frac:g}"}
-        print(json.dumps(result), flush=True)  # keep the best completed sample even if killed later
-        if (time.perf_counter() - t_start) + dt * 4.4 > budget_s:   # the next sample has 4x the tokens
-            break
+        hc = h - h % cfg.patch_size
+        frac = (Hc * W) / (hc * w)
+        if full:
+            torch.save({"surf": {k: v.contiguous() for k, v in o_s.items()},
+                        "atmos": {k: v.contiguous() for k, v in o_a.items()}}, out_path)
+            sample = (f"CPU oracle (fp32 port of the reference forward, 1.3B-parameter model, the GPU step's weights and "
+                      f"Batch) on the full {hc}x{w} grid: one forward in {dt:.1f} s")
+        else:
+            sample = (f"CPU oracle on a {hc}x{w} sub-grid = 1/{frac:g} of the tokens in {dt:.2f} s; value = that rate / "
+                      f"{frac:g} (FALL-BACK: the full grid did not finish in its budget)")
+        print(json.dumps({"value": 1.0 / (dt * frac), "unit": "forecast-steps/s", "cores": threads, "kind": "port",
+                          "sample": sample, "full_grid": bool(full), "seconds": dt}), flush=True)
+        if not full and (time.perf_counter() - t_start) + dt * frac * 1.3 > budget_s:
+            break   # the full grid would not fit: keep the fall-back sample
 
 
-def cpu_baseline(budget_s: float = 200.0) -> dict:
-    """Run `cpu_worker` in a subprocess with a hard timeout (the 256-thread GPU hosts have stalled
-    for minutes inside CPU torch ops); the last complete sample wins.  The worker times the 1/16 grid, then the 1/4
-    grid (360 x 720) if the first took under ~35 s, then the full grid if that took under ~35 s too."""
+def cpu_baseline(model, H: int, W: int, budget_s: float) -> tuple[dict, dict | None]:
+    """Run `cpu_worker` in a subprocess with a hard timeout (the 256-thread GPU hosts have stalled for minutes inside CPU
+    torch ops).  Returns (cpu_baseline object, oracle outputs of the full grid or None)."""
     import subprocess
 
     threads = min(os.cpu_count() or 1, 64)
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-worker", "--cpu-budget", str(budget_s - 20),
-           "--cpu-threads", str(threads)]
+    tmp = _tmp_dir()
+    wpath, opath = tmp / f"aurora_bench_weights_{os.getpid()}.pt", tmp / f"aurora_bench_oracle_{os.getpid()}.pt"
+    outputs = None
     try:
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s,
-                             env={**os.environ, "OMP_NUM_THREADS": str(threads), "HIP_VISIBLE_DEVICES": ""})
-        out = res.stdout
-    except subprocess.TimeoutExpired as e:
-        out = (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
-    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-    if not lines:
-        return {"value": None, "unit": "forecast-steps/s", "cores": threads, "kind": "port",
-                "sample": f"no CPU sample finished within {budget_s:.0f} s"}
-    return json.loads(lines[-1])
+        torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, wpath)
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-worker", "--cpu-budget", str(budget_s - 30),
+               "--cpu-threads", str(threads), "--cpu-weights", str(wpath), "--cpu-out", str(opath), "--grid", f"{H}x{W}"]
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s,
+                                 env={**os.environ, "OMP_NUM_THREADS": str(threads), "HIP_VISIBLE_DEVICES": ""})
+            out, err = res.stdout, res.stderr
+        except subprocess.TimeoutExpired as e:
+            dec = lambda x: x.decode() if isinstance(x, bytes) else (x or "")  # noqa: E731
+            out, err = dec(e.stdout), dec(e.stderr)
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if not lines:
+            log("CPU worker produced nothing:\n" + err[-2000:])
+            return {"value": None, "unit": "forecast-steps/s", "cores": threads, "kind": "port",
+                    "sample": f"no CPU sample finished within {budget_s:.0f} s"}, None
+        result = json.loads(lines[-1])
+        if result.get("full_grid") and opath.exists():
+            outputs = torch.load(opath, map_location="cpu", weights_only=True)
+        return result, outputs
+    finally:
+        for f in (wpath, opath):
+            try:
+                f.unlink()
+            except OSError:
+                pass
+
+
+TOL_FP32, TOL_BF16 = 1e-4, 5e-3   # reference tests/test_model.py:52-61 accepts 1e-4 (smooth) ... 5e-3 (winds, humidity)
+
+
+def mean_rel_err(pred, ref_surf: dict, ref_atmos: dict) -> dict:
+    """Per variable mean|out - ref| / mean|ref| (the metric of the reference's tests/test_model.py:45-61), on the device."""
+    out = {}
+    for d, rd in ((pred.surf_vars, ref_surf), (pred.atmos_vars, ref_atmos)):
+        for k, v in d.items():
+            r = rd[k].to(v.device).reshape(v.shape).double()
+            out[k] = ((v.double() - r).abs().mean() / (r.abs().mean() + 1e-30)).item()
+    return out
+
+
+def full_grid_parity(model, batch, pred_bf16, oracle_out: dict) -> dict:
+    """GPU step vs the CPU oracle on the whole grid: the timed bf16 (autocast) engine, and the fp32 engine on the same
+    weights (a second handle; the parameters are shared, not copied)."""
+    import aurora_amd
+
+    e16 = mean_rel_err(pred_bf16, oracle_out["surf"], oracle_out["atmos"])
+    with torch.device("meta"):
+        m32 = aurora_amd.AuroraPretrained(autocast=False)
+    m32.load_state_dict(model.state_dict(), assign=True)
+    m32 = m32.eval()
+    with torch.inference_mode():
+        pred32 = m32.forward(batch)
+    torch.cuda.synchronize()
+    e32 = mean_rel_err(pred32, oracle_out["surf"], oracle_out["atmos"])
+    del m32
+    H, W = next(iter(pred32.surf_vars.values())).shape[-2:]
+    w32, w16 = max(e32.values()), max(e16.values())
+    return {"grid": f"{H}x{W}", "metric": "max over variables of mean|out - oracle| / mean|oracle| "
+                                          "(reference tests/test_model.py:45-61)",
+            "fp32_engine_vs_oracle": w32, "bf16_engine_vs_oracle": w16, "tol_fp32": TOL_FP32, "tol_bf16": TOL_BF16,
+            "per_variable_fp32": e32, "per_variable_bf16": e16, "ok": bool(w32 <= TOL_FP32 and w16 <= TOL_BF16)}
+
+
+def launch_command(args, argv: list[str]) -> list[str]:
+    """`python bench.py --gpus N` without a launcher: the torch.distributed.run command that starts the N ranks."""
+    import socket
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), *argv]
 
 
 def main() -> None:
@@ -151,18 +239,33 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=900.0,
+                    help="seconds the CPU oracle leg may take (full grid: ~5 min on 64 cores)")
+    ap.add_argument("--grid", default="721x1440", help=argparse.SUPPRESS)   # tests run the same script on a small grid
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-budget", type=float, default=24.0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-weights", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    GH, GW = map(int, args.grid.split("x"))
     if args.cpu_worker:
-        cpu_worker(args.cpu_budget, args.cpu_threads)
+        cpu_worker(args.cpu_budget, args.cpu_threads, args.cpu_weights, args.cpu_out, GH, GW)
         return
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher of the N ranks (one process per GPU)
+        import subprocess
+
+        cmd = launch_command(args, sys.argv[1:])
+        log("launching " + " ".join(cmd))
+        sys.exit(subprocess.run(cmd, env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"}).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if distributed:
         import torch.distributed as dist
 
@@ -174,11 +277,12 @@ def main() -> None:
         # AURORA_BENCH_BACKEND=gloo replaces RCCL (which needs one GPU per rank) by host-staged gloo.
         if os.environ.get("AURORA_BENCH_SAME_GPU"):
             local_rank = 0
+        elif torch.cuda.device_count() < world:
+            raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()}")
         backend = os.environ.get("AURORA_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend, timeout=timedelta(seconds=300), **kw)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+        dist.init_process_group(backend, timeout=timedelta(seconds=600), **kw)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -190,11 +294,11 @@ def main() -> None:
     if mode == "bands":
         # one forecast, identical inputs everywhere; each rank keeps its latitude band resident
         model.configure_sharding(rank, world, gather_output=False)
-        full = synthetic_batch(model.config, 721, 1440, 1, device)
+        full = synthetic_batch(model.config, GH, GW, 1, device)
         batch = model.engine().local_band(full.crop(model.patch_size))
         del full
     else:
-        batch = synthetic_batch(model.config, 721, 1440, 1 + rank, device)
+        batch = synthetic_batch(model.config, GH, GW, 1 + (rank if mode == "replicas" else 0), device)
     log("batch on device")
 
     def barrier():
@@ -216,10 +320,10 @@ def main() -> None:
         elapsed = time.perf_counter() - t0
         log(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
         # (2) the same K steps again with HIP events (on the launch stream, inside the C-ABI handle) around every launch
-        # of the two roofline kernels -> `roofline`.  Kept out of (1): an event pair keeps a launch from overlapping
+        # of the roofline kernels -> `roofline`.  Kept out of (1): an event pair keeps a launch from overlapping
         # its neighbours, ~250 pairs per step cost about 1 % of it.
         eng = model.engine()
-        eng.profile_start({"linear_bf16", "window_attention_bf16"})
+        eng.profile_start({"linear_bf16", "linear_layernorm_bf16", "window_attention_bf16"})
         for _ in range(args.steps):
             model.forward(batch)
         barrier()
@@ -234,26 +338,33 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    failed = False
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = (1 if mode == "bands" else world) * args.steps / elapsed
-        g = prof.get("linear_bf16", {"launches": 0, "ms": 0.0, "work": 0.0})
-        a = prof.get("window_attention_bf16", {"launches": 0, "ms": 0.0, "work": 0.0})
+        zero = {"launches": 0, "ms": 0.0, "work": 0.0}
+        g = prof.get("linear_bf16", zero)
+        f = prof.get("linear_layernorm_bf16", zero)
+        a = prof.get("window_attention_bf16", zero)
         gemm_tf = g["work"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else 0.0
+        all_tf = (g["work"] + f["work"]) / ((g["ms"] + f["ms"]) * 1e-3) / 1e12 if g["ms"] + f["ms"] else 0.0
         attn_gbs = a["work"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] else 0.0
         # HBM-side bytes per launch of the dominant kernel come from hardware counters, which only rocprofv3 can collect:
-        # the tracked PMC summary of THIS command (tools/profile_round.sh -> tools/pmc_rollup.py), not a live value.
-        traffic = None
+        # the tracked PMC summary of THIS command (tools/profile_round.sh -> tools/pmc_rollup.py), not a live value --
+        # `traffic_build` names the commit whose library those passes profiled.
+        traffic, traffic_build = None, None
         pmc = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))
         if pmc:
-            traffic = json.loads(pmc[-1].read_text()).get("linear_bf16_hbm_bytes_per_launch")
+            pj = json.loads(pmc[-1].read_text())
+            traffic, traffic_build = pj.get("linear_bf16_hbm_bytes_per_launch"), pj.get("build_commit")
+        per = max(args.steps, 1)
         out = {
             "metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13",
             "value": value, "unit": "forecast-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if mode == "bands" else "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": "AuroraPretrained(autocast=True) 1.3B, 0.25deg ERA5 721x1440, 13 levels, "
+            "config": {"workload": f"AuroraPretrained(autocast=True) 1.3B, 0.25deg ERA5 {GH}x{GW}, 13 levels, "
                                    "T=2, batch 1 per GPU, one forward step (BASELINE.json configs[1])",
                        "parallelism": {"single": "1 GPU",
                                        "bands": f"one forecast over {world} latitude bands, RCCL halo exchange "
@@ -261,25 +372,35 @@ def main() -> None:
                                        "replicas": f"replica x{world} (independent forecasts, no data-path "
                                                    "collective)"}[mode]},
             "roofline": {
-                "kernel": "linear_kernel_256pp (bf16 MFMA GEMM, ping-pong LDS ring; the 174 plain backbone linears of a step -- the 24 stage-0 proj / fc2 launches are fused with their AdaLN + residual: kernel_ms_per_step.linear_layernorm_bf16)", "bound": "mfma",
+                "kernel": "linear_kernel_256pp (bf16 MFMA GEMM, ping-pong LDS ring): the plain backbone linears of a step; "
+                          "`frac_all_matrix_launches` adds the stage-0 proj / fc2 launches that run fused with their "
+                          "AdaLN + residual (linear_layernorm_bf16)", "bound": "mfma",
                 "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_source": f"profiles/{pmc[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command; "
                                   "2 x FETCH_SIZE per profiles/r02_fetch_calibration.txt)" if pmc else None,
+                "traffic_build": traffic_build,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_GEMM_LAUNCH,
-                "launches_per_step": g["launches"] / max(args.steps, 1),
-                "ms_per_step": g["ms"] / max(args.steps, 1),
+                "launches_per_step": g["launches"] / per, "ms_per_step": g["ms"] / per,
+                "frac_all_matrix_launches": all_tf / PEAK_BF16_TFLOPS,
+                "all_matrix_launches": {"achieved": all_tf, "launches_per_step": (g["launches"] + f["launches"]) / per,
+                                        "ms_per_step": (g["ms"] + f["ms"]) / per},
                 "attention": {"kernel": "window_attention_bf16", "bound": "hbm", "achieved": attn_gbs,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": attn_gbs / PEAK_HBM_GBS,
-                              "launches_per_step": a["launches"] / max(args.steps, 1),
-                              "ms_per_step": a["ms"] / max(args.steps, 1)},
+                              "launches_per_step": a["launches"] / per, "ms_per_step": a["ms"] / per},
             },
-            "step_tflops": FLOP_PER_STEP / (ms_per_step * 1e-3) / 1e12,
+            "step_tflops": FLOP_PER_STEP / (ms_per_step * 1e-3) / 1e12 if (GH, GW) == (721, 1440) else None,
             "kernel_ms_per_step": {k: v["ms"] for k, v in sorted(breakdown.items())},   # (the extra, un-timed step)
         }
         if world == 1 and not args.no_cpu_baseline:
-            log("timing the CPU oracle sample")
-            out["cpu_baseline"] = cpu_baseline()
+            log("running the CPU oracle on the same weights and Batch (full grid)")
+            out["cpu_baseline"], oracle_out = cpu_baseline(model, GH, GW, args.cpu_budget)
+            if oracle_out is not None:
+                log("comparing the GPU step with the oracle")
+                out["parity_full_grid"] = full_grid_parity(model, batch, pred, oracle_out)
+                failed = not out["parity_full_grid"]["ok"]
+            else:
+                out["parity_full_grid"] = None
             # The real reference (microsoft/aurora itself) cannot run on this box (no /root/reference here): its
             # timing, and the port's on the same machine and inputs, come from tools/time_reference.py in the build
             # container (tracked file, full 721 x 1440 grid).
@@ -296,6 +417,9 @@ def main() -> None:
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        log("FULL-GRID PARITY VIOLATED (see parity_full_grid in the JSON line)")
+        sys.exit(1)
 
 
 if __name__ == "__main__":

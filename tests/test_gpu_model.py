@@ -81,7 +81,7 @@ def test_bf16_engine_within_autocast_tolerance(name):
             base[f"{kind}.{k}"] = helpers.mean_rel_err(od[k], ref)
     print(name, "engine bf16:", max(errs.values()), " reference autocast:", max(base.values()))
     for k in errs:
-        assert errs[k] < 3e-2, (k, errs[k])
+        assert errs[k] < 1e-2, (k, errs[k])
         assert errs[k] < 3 * base[k] + 1e-3, (k, errs[k], base[k])
 
 
@@ -215,3 +215,20 @@ def test_rollout_to_host_overlaps_and_equals_device_rollout():
             assert torch.equal(h.surf_vars[k], v.cpu()), k
         for k, v in d.atmos_vars.items():
             assert torch.equal(h.atmos_vars[k], v.cpu()), k
+
+
+def test_write_rollout_files_equal_the_predictions(tmp_path):
+    """`write_rollout` = roll-out + pinned-host delivery + one netCDF file per step written by a
+    background thread; the files hold exactly what `rollout` yields."""
+    case, model, batch = build("base_pad")
+    with torch.inference_mode():
+        want = [p.to("cpu") for p in rollout(model, batch, steps=3)]
+        paths = aurora_amd.write_rollout(model, batch, 3, str(tmp_path / "pred.{step:02d}.nc"))
+    assert [p.rsplit("/", 1)[1] for p in paths] == ["pred.01.nc", "pred.02.nc", "pred.03.nc"]
+    for path, ref in zip(paths, want):
+        got = Batch.from_netcdf(path)
+        assert got.metadata.rollout_step == ref.metadata.rollout_step
+        assert tuple(got.metadata.time) == tuple(t.replace(tzinfo=None) for t in ref.metadata.time)
+        for d, rd in ((got.surf_vars, ref.surf_vars), (got.atmos_vars, ref.atmos_vars)):
+            for k, v in rd.items():
+                assert torch.equal(d[k], v), k
