@@ -150,6 +150,55 @@ void fourier(Expansion kind, const double* x, int64_t n, int d, float* out) {
   }
 }
 
+// Fourier position / scale features of the patch grid (posencoding.py:61-192): [L][D] each, L = Hp * Wp.
+// Patch-mean position and patch root area in fp32 like the reference, the trigonometry in fp64 (the reference's fp32
+// torch kernels are not reproducible bit for bit outside torch; callers who need that pass the encodings in).
+void pos_scale_tables(const double* lat, const double* lon, int Hp, int Wp, int P, int D, float* pos_out, float* scale_out) {
+  const int64_t Lp = (int64_t)Hp * Wp;
+  std::vector<double> mid_lat(Hp), mid_lon(Wp), area_lat(Hp), area_lon(Wp);
+  const float rad = (float)(PI / 180.0);
+  for (int hp = 0; hp < Hp; ++hp) {
+    float sum = 0.f, mx = -INFINITY, mn = INFINITY;
+    for (int i = 0; i < P; ++i) {
+      const float v = (float)lat[hp * P + i];
+      for (int j = 0; j < P; ++j) sum += v;   // avg_pool2d sums the P x P window of the broadcast grid in fp32
+      mx = fmaxf(mx, v); mn = fminf(mn, v);
+    }
+    REQUIRE(mx > mn, "latitudes of a patch must differ");
+    mid_lat[hp] = (double)(sum / (float)(P * P));
+    area_lat[hp] = (double)((float)sin((double)(mx * rad)) - (float)sin((double)(mn * rad)));
+  }
+  for (int wp = 0; wp < Wp; ++wp) {
+    float sum = 0.f, mx = -INFINITY, mn = INFINITY;
+    for (int i = 0; i < P; ++i)
+      for (int j = 0; j < P; ++j) sum += (float)lon[wp * P + j];
+    for (int j = 0; j < P; ++j) {
+      const float v = (float)lon[wp * P + j];
+      mx = fmaxf(mx, v); mn = fminf(mn, v);
+    }
+    REQUIRE(mx > mn, "longitudes of a patch must differ");
+    mid_lon[wp] = (double)(sum / (float)(P * P));
+    area_lon[wp] = (double)(mx * rad - mn * rad);
+  }
+  std::vector<double> xs(Lp), ys(Lp), ra(Lp);
+  for (int hp = 0; hp < Hp; ++hp)
+    for (int wp = 0; wp < Wp; ++wp) {
+      const int64_t l = (int64_t)hp * Wp + wp;
+      // avg_pool2d over a P x P patch of a separable grid: mean over rows of the (constant per row) latitudes
+      xs[l] = mid_lat[hp];
+      ys[l] = mid_lon[wp];
+      const float area = (float)(6371.0 * 6371.0 * PI) * (float)area_lat[hp] * (float)area_lon[wp];
+      REQUIRE(area > 0, "patch areas must be positive");
+      ra[l] = (double)sqrtf(area);
+    }
+  std::vector<float> half((size_t)Lp * (D / 2));
+  fourier(POS, xs.data(), Lp, D / 2, half.data());
+  for (int64_t l = 0; l < Lp; ++l) memcpy(&pos_out[(size_t)l * D], &half[(size_t)l * (D / 2)], (D / 2) * 4);
+  fourier(POS, ys.data(), Lp, D / 2, half.data());
+  for (int64_t l = 0; l < Lp; ++l) memcpy(&pos_out[(size_t)l * D + D / 2], &half[(size_t)l * (D / 2)], (D / 2) * 4);
+  fourier(SCALE, ra.data(), Lp, D, scale_out);
+}
+
 // Window token / group tables of one block flavour (the closed form of the reference's roll -> pad -> partition chain
 // and mask, swin3d.py:177-360, 471-505; Python twin: aurora_amd/engine/geometry.py, tests/test_geometry.py).
 struct Res { int c, h, w; };
@@ -1344,6 +1393,16 @@ extern "C" int aurora_hip_finalize(aurora_hip_model* mp, void* stream) {
   })
 }
 
+extern "C" int aurora_hip_pos_scale_encoding(const double* lat, const double* lon, int n_lat, int n_lon, int patch_size,
+                                             int embed_dim, float* pos_out, float* scale_out) {
+  GUARDED({
+    REQUIRE(lat && lon && pos_out && scale_out, "pos_scale_encoding: null argument");
+    REQUIRE(patch_size > 0 && n_lon % patch_size == 0 && n_lat >= patch_size && embed_dim % 4 == 0,
+            "pos_scale_encoding: bad grid %d x %d for patch size %d / embed_dim %d", n_lat, n_lon, patch_size, embed_dim);
+    pos_scale_tables(lat, lon, n_lat / patch_size, n_lon / patch_size, patch_size, embed_dim, pos_out, scale_out);
+  })
+}
+
 extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid* g, void* stream) {
   GUARDED({
     REQUIRE(mp && g, "precompute: null argument");
@@ -1372,50 +1431,7 @@ extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid
       memcpy(scale.data(), g->scale_encoding, scale.size() * 4);
     } else {
       REQUIRE(g->lat && g->lon, "precompute: latitudes / longitudes (or the encodings themselves) are required");
-      // patch-mean position and patch root area in fp32 like the reference, the trigonometry in fp64 (the reference's
-      // fp32 torch kernels are not reproducible bit for bit outside torch; callers who need that pass the encodings in)
-      std::vector<double> mid_lat(m.Hp), mid_lon(m.Wp), area_lat(m.Hp), area_lon(m.Wp);
-      const float rad = (float)(PI / 180.0);
-      for (int hp = 0; hp < m.Hp; ++hp) {
-        float sum = 0.f, mx = -INFINITY, mn = INFINITY;
-        for (int i = 0; i < P; ++i) {
-          const float v = (float)g->lat[hp * P + i];
-          for (int j = 0; j < P; ++j) sum += v;   // avg_pool2d sums the P x P window of the broadcast grid in fp32
-          mx = fmaxf(mx, v); mn = fminf(mn, v);
-        }
-        REQUIRE(mx > mn, "latitudes of a patch must differ");
-        mid_lat[hp] = (double)(sum / (float)(P * P));
-        area_lat[hp] = (double)((float)sin((double)(mx * rad)) - (float)sin((double)(mn * rad)));
-      }
-      for (int wp = 0; wp < m.Wp; ++wp) {
-        float sum = 0.f, mx = -INFINITY, mn = INFINITY;
-        for (int i = 0; i < P; ++i)
-          for (int j = 0; j < P; ++j) sum += (float)g->lon[wp * P + j];
-        for (int j = 0; j < P; ++j) {
-          const float v = (float)g->lon[wp * P + j];
-          mx = fmaxf(mx, v); mn = fminf(mn, v);
-        }
-        REQUIRE(mx > mn, "longitudes of a patch must differ");
-        mid_lon[wp] = (double)(sum / (float)(P * P));
-        area_lon[wp] = (double)(mx * rad - mn * rad);
-      }
-      std::vector<double> xs(Lp), ys(Lp), ra(Lp);
-      for (int hp = 0; hp < m.Hp; ++hp)
-        for (int wp = 0; wp < m.Wp; ++wp) {
-          const int64_t l = (int64_t)hp * m.Wp + wp;
-          // avg_pool2d over a P x P patch of a separable grid: mean over rows of the (constant per row) latitudes
-          xs[l] = mid_lat[hp];
-          ys[l] = mid_lon[wp];
-          const float area = (float)(6371.0 * 6371.0 * PI) * (float)area_lat[hp] * (float)area_lon[wp];
-          REQUIRE(area > 0, "patch areas must be positive");
-          ra[l] = (double)sqrtf(area);
-        }
-      std::vector<float> half((size_t)Lp * (D / 2));
-      fourier(POS, xs.data(), Lp, D / 2, half.data());
-      for (int64_t l = 0; l < Lp; ++l) memcpy(&pos[(size_t)l * D], &half[(size_t)l * (D / 2)], (D / 2) * 4);
-      fourier(POS, ys.data(), Lp, D / 2, half.data());
-      for (int64_t l = 0; l < Lp; ++l) memcpy(&pos[(size_t)l * D + D / 2], &half[(size_t)l * (D / 2)], (D / 2) * 4);
-      fourier(SCALE, ra.data(), Lp, D, scale.data());
+      pos_scale_tables(g->lat, g->lon, m.Hp, m.Wp, P, D, pos.data(), scale.data());
     }
     {
       DevBuf d_pos = to_device(pos), d_scale = to_device(scale), pe((size_t)Lp * D * 4);

@@ -546,5 +546,6 @@ _SIGNATURES.update({
     "aurora_hip_set_time": (c_int, [c_void_p, _PD, c_int, c_void_p]),
     "aurora_hip_step": (c_int, [c_void_p, ctypes.POINTER(HipStepIO), c_void_p]),
     "aurora_hip_workspace_bytes": (c_int64, [c_void_p]),
+    "aurora_hip_pos_scale_encoding": (c_int, [_PD, _PD, c_int, c_int, c_int, c_int, _PF, _PF]),
 })
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -367,6 +367,13 @@ int aurora_hip_finalize(aurora_hip_model* model, void* stream);
 int aurora_hip_save_packed(aurora_hip_model* model, const char* path, void* stream);
 int aurora_hip_load_packed(aurora_hip_model* model, const char* path);
 int aurora_hip_precompute(aurora_hip_model* model, const aurora_hip_grid* grid, void* stream);
+/* The position / scale tables aurora_hip_precompute derives from lat / lon when the grid carries no tables of its own
+ * (posencoding.py:61-192; HOST pointers in and out, no device work): pos_out and scale_out are
+ * [(n_lat / patch) * (n_lon / patch)][embed_dim] floats; a surplus latitude row is ignored.  Float32 geometry as upstream,
+ * fp64 trigonometry -- equal to the reference's torch tables except where its float32 sin / sqrt differ in the last ulp,
+ * which the shortest wavelengths amplify (tests/test_encodings.py states the bound per wavelength). */
+int aurora_hip_pos_scale_encoding(const double* lat, const double* lon, int n_lat, int n_lon, int patch_size,
+                                  int embed_dim, float* pos_out, float* scale_out);
 /* Absolute times of the batch elements in hours since the Unix epoch (encoder.py:359-363), host pointer. */
 int aurora_hip_set_time(aurora_hip_model* model, const double* time_hours, int B, void* stream);
 int aurora_hip_step(aurora_hip_model* model, const aurora_hip_step_io* io, void* stream);

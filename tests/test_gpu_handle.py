@@ -202,3 +202,19 @@ def test_c_abi_argument_errors():
     assert L.aurora_hip_create(ctypes.byref(c), ctypes.byref(h)) == -1      # zero stages
     assert b"stages" in L.aurora_hip_last_error()
     assert L.aurora_hip_step(None, None, None) == -1
+
+
+@pytest.mark.parametrize("mode", ["bf16", "native", "f16"])
+def test_c_abi_rollout_under_a_pinned_fp32_gemm_mode(mode):
+    """AURORA_F32_GEMM pins how the large fp32 linears are multiplied (include/aurora_hip.h) -- a process-wide default, so
+    the goldens are re-run in a child process per mode.  (A pinned mode once made the handle's resampler pass a guard
+    to mode-1 launches, which then skipped to_kv / to_out: the results were garbage, and no test set the variable.)"""
+    import os
+    import subprocess
+    import sys
+
+    res = subprocess.run(
+        [sys.executable, "-m", "pytest", __file__, "-q", "-x", "-p", "no:cacheprovider", "-k",
+         "test_c_abi_rollout_matches_reference_golden and (base_pad or stabilised_12h)"],
+        env={**os.environ, "AURORA_F32_GEMM": mode}, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "2 passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
