@@ -59,7 +59,20 @@ struct LinearArgs {
   int vec_store;                  // 1: every C/C2/res row piece is 16-byte aligned
   const float* guard; float guard_limit;   // f32 split kernels (guarded launch): two fp16 terms iff *guard < guard_limit
   int out_split;                  // two-term ping-pong kernel: C is written in the fp16-pair layout (see aurora_hip_split_f16)
+  // strided batch (aurora_hip_linear_batched): problem blockIdx.y adds these to A / W / C (bytes) and bias (floats)
+  int64_t bs_a, bs_w, bs_c, bs_bias;
 };
+
+// The problem of a strided batch this workgroup belongs to (blockIdx.y; a plain launch has one problem and zero strides).
+__device__ __forceinline__ LinearArgs batch_problem(const LinearArgs& in) {
+  LinearArgs p = in;
+  const int64_t g = blockIdx.y;
+  p.A += g * in.bs_a;
+  p.W += g * in.bs_w;
+  p.C += g * in.bs_c;
+  if (in.bias) p.bias += g * in.bs_bias;
+  return p;
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -126,7 +139,8 @@ template <> struct Other<float> { typedef bf16_t type; };
 template <> struct Other<bf16_t> { typedef float type; };
 
 template <typename T>
-__global__ __launch_bounds__(THREADS, 2) void linear_kernel(const LinearArgs p) {
+__global__ __launch_bounds__(THREADS, 2) void linear_kernel(const LinearArgs p_in) {
+  const LinearArgs p = batch_problem(p_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // Per buffer: X tile then W tile; 2 buffers.
   auto lds_x = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
@@ -511,7 +525,8 @@ __device__ __forceinline__ void epilogue_256_f32_coalesced(const LinearArgs& p, 
 // holds 128 accumulator registers, the kernel needs ~250 of the 256 a wave gets at two waves per SIMD.)
 // PRIO: static s_setprio(1) for the second-dispatched half of the waves (the arbitration loser of every K-stage).
 template <typename T, int WN, int NST, int PRIO = 0>
-__global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArgs p) {
+__global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArgs p_in) {
+  const LinearArgs p = batch_problem(p_in);
   constexpr int NTHR = 128 * WN;
   constexpr int XP = (BM2 * 4) / NTHR;            // 16-byte pieces of the activation tile per thread and stage
   constexpr int WP = (64 * WN * 4) / NTHR;        // ... of the weight tile (= 2)
@@ -703,7 +718,8 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
 // lgkmcnt(0) before its barrier) is at least one barrier in the past for early and late waves alike.
 // =================================================================================================
 template <int PRIO>
-__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearArgs p) {
+__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearArgs p_in) {
+  const LinearArgs p = batch_problem(p_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -885,7 +901,8 @@ __device__ __forceinline__ f32x4 mma_f16(u32x4 a, u32x4 b, f32x4 c) {
 }
 
 template <int TERMS>   // 3: three bf16 terms, six MFMAs;  2: two fp16 terms, three MFMAs
-__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const LinearArgs p) {
+__global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const LinearArgs p_in) {
+  const LinearArgs p = batch_problem(p_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // Guarded launch: the host has launched BOTH variants; the word the caller left in device memory (max |activation|
   // or a bound of it) decides which one does the work -- two fp16 terms inside the safe range, three bf16 terms
@@ -1068,7 +1085,8 @@ constexpr int VM = 128, VN = 256, VROW = 128, VTHREADS = 512, VNST = 3;
 constexpr int VOPER_X = VM * VROW, VOPER_W = VN * VROW, VSTAGE = VOPER_X + VOPER_W;   // 16 + 32 = 48 KiB
 
 template <bool A_PRE, bool W_PRE>   // operand already in the fp16-pair layout: its split (all of its VALU work) disappears
-__global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearArgs p) {
+__global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearArgs p_in) {
+  const LinearArgs p = batch_problem(p_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.guard != nullptr && !(*p.guard < p.guard_limit)) return;   // guarded launch: the three-term kernel does the work
   const int tid = threadIdx.x;
@@ -1576,11 +1594,39 @@ extern "C" int aurora_hip_linear(const void* A, int64_t lda, const void* W, int6
                               0.f, stream);
 }
 
+namespace {
+int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, void* C2,
+                int64_t ldc2, const float* residual, int64_t ldr, int64_t M, int N, int K, int dtype, int act, int f32_gemm,
+                const float* guard, float guard_limit, int batch, int64_t stride_a, int64_t stride_w, int64_t stride_bias,
+                int64_t stride_c, void* stream);
+}
+
 extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, int64_t ldw,
                                     const float* bias, void* C, int64_t ldc, void* C2, int64_t ldc2,
                                     const float* residual, int64_t ldr, int64_t M, int N, int K,
                                     int dtype, int act, int f32_gemm, const float* guard, float guard_limit,
                                     void* stream) {
+  return linear_impl(A, lda, W, ldw, bias, C, ldc, C2, ldc2, residual, ldr, M, N, K, dtype, act, f32_gemm, guard, guard_limit,
+                     1, 0, 0, 0, 0, stream);
+}
+
+extern "C" int aurora_hip_linear_batched(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
+                                         int64_t ldc, int64_t M, int N, int K, int dtype, int act, int f32_gemm,
+                                         const float* guard, float guard_limit, int batch, int64_t stride_a,
+                                         int64_t stride_w, int64_t stride_bias, int64_t stride_c, void* stream) {
+  AURORA_CHECK_ARG(batch >= 1 && batch <= 65535, "linear_batched: 1 <= batch <= 65535 (got %d)", batch);
+  const int es = dtype == AURORA_F32 ? 4 : 2;
+  AURORA_CHECK_ARG((stride_a * es) % 16 == 0 && (stride_w * es) % 16 == 0 && (stride_c * es) % 16 == 0 && stride_bias % 4 == 0,
+                   "linear_batched: batch strides must keep every problem 16-byte aligned");
+  return linear_impl(A, lda, W, ldw, bias, C, ldc, nullptr, 0, nullptr, 0, M, N, K, dtype, act, f32_gemm, guard, guard_limit,
+                     batch, stride_a, stride_w, stride_bias, stride_c, stream);
+}
+
+namespace {
+int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, void* C2,
+                int64_t ldc2, const float* residual, int64_t ldr, int64_t M, int N, int K, int dtype, int act, int f32_gemm,
+                const float* guard, float guard_limit, int batch, int64_t stride_a, int64_t stride_w, int64_t stride_bias,
+                int64_t stride_c, void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "linear: bad dtype %d", dtype);
   const int pre = f32_gemm < 0 ? 0 : f32_gemm & (AURORA_F32_A_SPLIT | AURORA_F32_W_SPLIT | AURORA_F32_C_SPLIT);
   if (pre) f32_gemm &= ~pre;
@@ -1662,7 +1708,8 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
   p.out_split = (pre & AURORA_F32_C_SPLIT) ? 1 : 0;
   AURORA_CHECK_ARG(p.n_blocks < (int64_t)1 << 31, "linear: too many tiles");
 
-  dim3 grid((unsigned)p.n_blocks);
+  p.bs_a = stride_a * es; p.bs_w = stride_w * es; p.bs_c = stride_c * es; p.bs_bias = stride_bias;
+  dim3 grid((unsigned)p.n_blocks, (unsigned)batch);
   static bool attr_done_dev[64] = {false};   // function attributes are per device
   bool& attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
@@ -1686,7 +1733,7 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
     q.k_tiles = K / 32;
     q.tiles_n = N / VN;
     q.n_blocks = ((M + VM - 1) / VM) * q.tiles_n;
-    const dim3 g((unsigned)q.n_blocks), b(VTHREADS);
+    const dim3 g((unsigned)q.n_blocks, (unsigned)batch), b(VTHREADS);
     if (pre & AURORA_F32_A_SPLIT) hipLaunchKernelGGL((linear_kernel_f32pp<true, true>), g, b, VNST * VSTAGE, as_stream(stream), q);
     else if (pre & AURORA_F32_W_SPLIT) hipLaunchKernelGGL((linear_kernel_f32pp<false, true>), g, b, VNST * VSTAGE, as_stream(stream), q);
     else hipLaunchKernelGGL((linear_kernel_f32pp<false, false>), g, b, VNST * VSTAGE, as_stream(stream), q);
@@ -1722,6 +1769,7 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
   }
   return check_launch("linear");
 }
+}  // namespace
 
 extern "C" int aurora_hip_split_f16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int K,
                                     float scale, void* stream) {

@@ -29,6 +29,7 @@
 #include <string>
 #include <vector>
 
+#include "band.h"
 #include "common.h"
 
 using namespace aurora;
@@ -197,59 +198,6 @@ void pos_scale_tables(const double* lat, const double* lon, int Hp, int Wp, int 
   fourier(POS, ys.data(), Lp, D / 2, half.data());
   for (int64_t l = 0; l < Lp; ++l) memcpy(&pos_out[(size_t)l * D + D / 2], &half[(size_t)l * (D / 2)], (D / 2) * 4);
   fourier(SCALE, ra.data(), Lp, D, scale_out);
-}
-
-// Window token / group tables of one block flavour (the closed form of the reference's roll -> pad -> partition chain
-// and mask, swin3d.py:177-360, 471-505; Python twin: aurora_amd/engine/geometry.py, tests/test_geometry.py).
-struct Res { int c, h, w; };
-struct WindowTables {
-  std::vector<int32_t> tok;
-  std::vector<uint8_t> grp;   // empty when the block is not shifted (or the grid fits one window)
-  int n_windows = 0, n_tok = 0;
-};
-WindowTables window_tables(Res res, const int window[3], bool shifted) {
-  const int dims[3] = {res.c, res.h, res.w};
-  int ws[3], ss[3], pad[3], front[3], nwin[3];
-  bool any_shift = false;
-  for (int a = 0; a < 3; ++a) {
-    ws[a] = window[a];
-    ss[a] = shifted ? window[a] / 2 : 0;
-    if (dims[a] <= window[a]) { ws[a] = dims[a]; ss[a] = 0; }   // util.py:53-71
-    pad[a] = (ws[a] - dims[a] % ws[a]) % ws[a];
-    front[a] = pad[a] / 2;                                       // two-sided padding, front = pad // 2
-    nwin[a] = (dims[a] + pad[a]) / ws[a];
-    any_shift |= ss[a] != 0;
-  }
-  auto label = [&](int a, int x) {   // swin3d.py:333-342
-    if (ss[a] == 0) return 2;
-    return x < dims[a] - ws[a] ? 0 : x < dims[a] - ss[a] ? 1 : 2;
-  };
-  WindowTables t;
-  t.n_windows = nwin[0] * nwin[1] * nwin[2];
-  t.n_tok = ws[0] * ws[1] * ws[2];
-  t.tok.resize((size_t)t.n_windows * t.n_tok);
-  if (any_shift) t.grp.resize(t.tok.size());
-  size_t at = 0;
-  for (int c1 = 0; c1 < nwin[0]; ++c1)
-    for (int h1 = 0; h1 < nwin[1]; ++h1)
-      for (int w1 = 0; w1 < nwin[2]; ++w1)
-        for (int wc = 0; wc < ws[0]; ++wc)
-          for (int wh = 0; wh < ws[1]; ++wh)
-            for (int ww = 0; ww < ws[2]; ++ww, ++at) {
-              const int r[3] = {c1 * ws[0] + wc - front[0], h1 * ws[1] + wh - front[1], w1 * ws[2] + ww - front[2]};
-              const bool valid = r[0] >= 0 && r[0] < dims[0] && r[1] >= 0 && r[1] < dims[1] && r[2] >= 0 && r[2] < dims[2];
-              int g = 0, o[3];
-              for (int a = 0; a < 3; ++a) {
-                o[a] = ((r[a] + ss[a]) % dims[a] + dims[a]) % dims[a];   // torch.roll(x, -s): rolled[i] = x[(i + s) % n]
-                const int cl = r[a] < 0 ? 0 : r[a] >= dims[a] ? dims[a] - 1 : r[a];
-                int la = label(a, cl);
-                if (a == 2 && la == 1) la = 2;   // longitude wraps: W slices 1 and 2 communicate
-                g = g * 3 + la;
-              }
-              t.tok[at] = valid ? (o[0] * res.h + o[1]) * res.w + o[2] : -1;
-              if (any_shift) t.grp[at] = (uint8_t)(valid ? g : 27);
-            }
-  return t;
 }
 
 // ---- the model -----------------------------------------------------------------------------------

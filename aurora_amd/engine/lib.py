@@ -54,6 +54,9 @@ _SIGNATURES = {
     "aurora_hip_linear_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                      c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                      c_int, c_int, c_void_p, c_float, c_void_p]),
+    "aurora_hip_linear_batched": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                          c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_int64, c_int64, c_int64,
+                                          c_int64, c_void_p]),
     "aurora_hip_absmax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "aurora_hip_linear_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_float,
@@ -530,6 +533,12 @@ class HipProfileEntry(ctypes.Structure):
     _fields_ = [("kernel", ctypes.c_char_p), ("launches", c_int64), ("ms", ctypes.c_double), ("work", ctypes.c_double)]
 
 
+class HipPlanInfo(ctypes.Structure):
+    _fields_ = [("n_windows", c_int32), ("win_tokens", c_int32), ("n_own", c_int32), ("n_halo", c_int32),
+                ("n_interior", c_int32), ("recv_offset", c_int32 * 2), ("recv_count", c_int32 * 2),
+                ("send_count", c_int32 * 2), ("has_groups", c_int32)]
+
+
 PROFILE_KINDS = ("linear_bf16", "linear_f32", "window_attention_bf16", "layernorm", "merge_ln", "split_ln", "patchify",
                  "perceiver_attention", "assemble_tokens", "unpatchify", "copy2d", "absmax", "linear_layernorm_bf16")
 
@@ -547,5 +556,10 @@ _SIGNATURES.update({
     "aurora_hip_step": (c_int, [c_void_p, ctypes.POINTER(HipStepIO), c_void_p]),
     "aurora_hip_workspace_bytes": (c_int64, [c_void_p]),
     "aurora_hip_pos_scale_encoding": (c_int, [_PD, _PD, c_int, c_int, c_int, c_int, _PF, _PF]),
+    "aurora_hip_band_partition": (c_int, [c_int, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32), c_int, c_int, c_int,
+                                          ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]),
+    "aurora_hip_band_plan": (c_int, [ctypes.POINTER(c_int32), ctypes.POINTER(c_int32), c_int, c_int, c_int,
+                                     ctypes.POINTER(c_int32), ctypes.POINTER(HipPlanInfo), c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
 })
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

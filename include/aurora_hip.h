@@ -75,6 +75,16 @@ int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, int64_t ldw,
                          int64_t M, int N, int K, int dtype, int act,
                          int f32_gemm, const float* guard, float guard_limit, void* stream);
 int aurora_hip_default_f32_gemm(void);
+/* `batch` independent problems of the same shape in ONE launch (strided batch): problem g reads A + g * stride_a,
+ * W + g * stride_w, bias + g * stride_bias and writes C + g * stride_c (strides in elements; every problem stays 16-byte
+ * aligned; stride 0 shares an operand).  Same kernels, modes and constraints as aurora_hip_linear_ex, no second output /
+ * residual.  Replaces the reference's per-level Python loops: LevelConditioned patch embeddings and heads
+ * (levelcond.py:36-69: one weight per pressure level) and the per-level bias of the atmospheric patch embedding
+ * (encoder.py:318-330). */
+int aurora_hip_linear_batched(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                              int64_t M, int N, int K, int dtype, int act, int f32_gemm, const float* guard,
+                              float guard_limit, int batch, int64_t stride_a, int64_t stride_w, int64_t stride_bias,
+                              int64_t stride_c, void* stream);
 
 /* Mode 2 with operands that are ALREADY split (flags OR-ed into f32_gemm = 2): the split is the same arithmetic wherever
  * it happens, so results are bit-identical to plain mode 2, but a GEMM whose operands arrive split spends no VALU work
@@ -283,8 +293,12 @@ int aurora_hip_convert(const void* src, void* dst, int64_t n, int src_dtype, voi
  *
  * Replaces `Aurora.forward` (aurora/model/aurora.py:265-392) = Perceiver3DEncoder.forward (encoder.py:198-366) +
  * Swin3DTransformerBackbone.forward (swin3d.py:884-936) + Perceiver3DDecoder.forward (decoder.py:168-276) with the
- * normalisation of Batch.normalise / unnormalise (batch.py:94-140) fused in, for the ERA5 model family (Aurora,
- * AuroraPretrained, AuroraSmallPretrained, Aurora12hPretrained, AuroraHighRes).  Call order:
+ * normalisation of Batch.normalise / unnormalise (batch.py:94-140) fused in, for EVERY public model class: Aurora,
+ * AuroraPretrained, AuroraSmallPretrained, Aurora12hPretrained, AuroraHighRes, and the variants AuroraAirPollution
+ * (level-conditioned embeddings / heads levelcond.py:36-69, dynamic and static inputs encoder.py:226-303, feature combiners
+ * and difference prediction aurora.py:726-796, second decoder Perceiver decoder.py:232-248) and AuroraWave (density / angle
+ * channels and their inverse, aurora.py:854-932).  A forecast can run on one device or as one latitude band of a
+ * sharded forecast (aurora_hip_set_band below).  Call order:
  *
  *   aurora_hip_create(&config, &model)
  *   aurora_hip_pack_weights(model, name, data, shape, ndim, AURORA_F32, on_device)   for every state_dict entry, after the
@@ -316,6 +330,26 @@ typedef struct aurora_hip_config {   /* Aurora.__init__ keywords, aurora/model/a
   const char* const* surf_vars;                              /* fixes the order of every per-variable array below */
   const char* const* static_vars;
   const char* const* atmos_vars;
+  /* ---- variant keywords (aurora.py:86-95); zero-initialised = the ERA5 model family -------------------------------
+   * variant: 0 base; 1 air pollution: positive variables go through the clamp + log feature combiner
+   * (`{surf,atmos}_feature_combiner.<var>` weights, aurora.py:733-742), variables in `modulation_heads` with an entry in
+   * difference_history predict a difference to that history state (aurora.py:761-779), SO2 is capped at the levels
+   * >= 850 hPa when LoRA is on (aurora.py:781-794); 2 ocean wave: `surf_vars` are the model's channels (`<v>_sin`,
+   * `<v>_cos`, `<v>_density`, ...), `surf_inputs` the variables the caller supplies after AuroraWave's
+   * batch_transform_hook; density / sin / cos channels are derived on the fly and inverted after the decoder
+   * (aurora.py:892-932; the water-body mask is the static variable "wmb"). */
+  int32_t variant;
+  int32_t n_level_condition;                                 /* levels with their own patch embedding / heads (levelcond.py) */
+  const double* level_condition;
+  int32_t dynamic_vars, atmos_static_vars, clamp_at_first_step, simulate_indexing_bug;
+  int32_t n_separate_perceiver;  const char* const* separate_perceiver;
+  int32_t n_modulation_heads;    const char* const* modulation_heads;
+  const int32_t* difference_history;                         /* [n_modulation_heads] history index, -1: no difference */
+  int32_t n_positive_surf;       const char* const* positive_surf_vars;
+  int32_t n_positive_atmos;      const char* const* positive_atmos_vars;
+  int32_t n_surf_inputs;         const char* const* surf_inputs;              /* wave only; 0: = surf_vars */
+  int32_t n_density;             const char* const* density_channel_surf_vars;
+  int32_t n_angle;               const char* const* angle_surf_vars;
 } aurora_hip_config;
 
 typedef struct aurora_hip_grid {     /* HOST pointers */
@@ -339,18 +373,22 @@ typedef struct aurora_hip_grid {     /* HOST pointers */
   const float* scale_encoding;
 } aurora_hip_grid;
 
-typedef struct aurora_hip_step_io {  /* DEVICE pointers; variable order = the config's */
+typedef struct aurora_hip_step_io {  /* DEVICE pointers; variable order = the config's (surf: surf_inputs for the wave variant) */
   int32_t B, T;                      /* batch size, history states given (<= max_history) */
-  const float* const* surf;          /* [n_surf]   each (B, T, n_lat, n_lon) with element strides surf_strides */
+  const float* const* surf;          /* [n_surf]   each (B, T, n_lat, n_lon) with element strides surf_strides; NULL entry = absent */
   int64_t surf_strides[4];
-  const float* const* stat;          /* [n_static] each (n_lat, n_lon) with element strides static_strides */
+  const float* const* stat;          /* [n_static] each (n_lat, n_lon) with element strides static_strides; NULL entry = absent */
   int64_t static_strides[2];
-  const float* const* atmos;         /* [n_atmos]  each (B, T, n_levels, n_lat, n_lon) with element strides atmos_strides */
+  const float* const* atmos;         /* [n_atmos]  each (B, T, n_levels, n_lat, n_lon) with element strides atmos_strides; NULL = absent */
   int64_t atmos_strides[5];
-  float* const* out_surf;            /* [n_surf]   each (B, H', n_lon) contiguous, H' = n_lat - n_lat % patch */
+  float* const* out_surf;            /* [n_out_surf] each (B, H', n_lon) contiguous, H' = n_lat - n_lat % patch; n_out_surf and the
+                                        order are aurora_hip_output_vars' (= the surface inputs, except for the wave variant) */
   float* const* out_atmos;           /* [n_atmos]  each (B, n_levels, H', n_lon) contiguous */
-  int32_t rollout_step;              /* Metadata.rollout_step of the input: selects the LoRA weight set (lora.py:105-129) */
+  int32_t rollout_step;              /* Metadata.rollout_step of the input: selects the LoRA weight set (lora.py:105-129) and
+                                        whether positive variables are clamped (aurora.py:368-388) */
 } aurora_hip_step_io;
+/* A band of a sharded forecast (aurora_hip_set_band) passes and receives ITS latitude rows only: n_lat above is then the
+ * band's row count, aurora_hip_band_rows tells which rows of the full grid those are. */
 
 int aurora_hip_create(const aurora_hip_config* config, aurora_hip_model** out);
 void aurora_hip_destroy(aurora_hip_model* model);
@@ -378,11 +416,74 @@ int aurora_hip_pos_scale_encoding(const double* lat, const double* lon, int n_la
 int aurora_hip_set_time(aurora_hip_model* model, const double* time_hours, int B, void* stream);
 int aurora_hip_step(aurora_hip_model* model, const aurora_hip_step_io* io, void* stream);
 int64_t aurora_hip_workspace_bytes(const aurora_hip_model* model);
+/* Names of the surface variables a step predicts, in the order of aurora_hip_step_io.out_surf (ocean wave: the non-angle
+ * variables, then the directions, aurora.py:914-932; otherwise the surface inputs).  Returns the count; `names` may be NULL. */
+int aurora_hip_output_vars(const aurora_hip_model* model, const char** names, int capacity);
+/* aurora_hip_set_time with the calendar fields the dynamic variables of the air-pollution model are made of
+ * (encoder.py:226-246): calendar[b] = {hour of day, weekday (Monday = 0), day of month}; NULL derives them from the time
+ * stamp as UTC. */
+int aurora_hip_set_time_ex(aurora_hip_model* model, const double* time_hours, const int32_t* calendar, int B, void* stream);
+
+/* ---- one forecast across several devices: latitude bands + halo exchange (the reference is
+ * single-device) ---------------------------------------------------------------------------------------------------------
+ * Every rank owns a contiguous band of latitude rows at every backbone stage (boundaries on the coarsest stage, doubled
+ * per finer stage, so patch merges / splits stay local).  Everything except window attention is local to a token, a 2 x 2
+ * block or a grid column.  A shifted-window block needs the k | v rows of the neighbouring band's first / last rows: the
+ * handle gathers them into `send` staging buffers, calls `post` (start sending / receiving; asynchronous to `stream`),
+ * attends the windows that need no halo row, calls `wait` (make `stream` wait for the messages), places the received rows
+ * and attends the boundary windows.  The TRANSPORT is the host's: RCCL point-to-point (torch.distributed / ncclSend /
+ * ncclRecv) in production, anything else in tests -- the library does not link a communication library.
+ * Message buffers are the four staging buffers the host hands over (its own allocations, so that its transport can
+ * address them): to / from the previous rank [0] and the next rank [1], `staging_bytes` each, at least
+ * aurora_hip_band_staging_bytes() (valid after aurora_hip_precompute).
+ * Call order: create, pack, finalize, aurora_hip_set_band, aurora_hip_precompute with the FULL grid, aurora_hip_band_rows,
+ * aurora_hip_set_band_staging, then steps on the band's rows. */
+typedef struct aurora_hip_halo_msg {
+  int32_t peer;       /* rank */
+  int32_t side;       /* 0: the previous rank's staging buffer, 1: the next rank's */
+  void* data;         /* device pointer inside that staging buffer */
+  int64_t bytes;
+} aurora_hip_halo_msg;
+typedef int (*aurora_hip_halo_post_fn)(void* user, const aurora_hip_halo_msg* sends, int32_t n_sends,
+                                       const aurora_hip_halo_msg* recvs, int32_t n_recvs, void* stream);
+typedef int (*aurora_hip_halo_wait_fn)(void* user, void* stream);
+typedef struct aurora_hip_band {
+  int32_t rank, world;
+  aurora_hip_halo_post_fn post;
+  aurora_hip_halo_wait_fn wait;
+  void* user;
+} aurora_hip_band;
+int aurora_hip_set_band(aurora_hip_model* model, const aurora_hip_band* band);   /* world <= 1: un-sharded again */
+/* Data rows [row0, row1) of the full (cropped) latitude axis that this rank owns. */
+int aurora_hip_band_rows(const aurora_hip_model* model, int32_t* row0, int32_t* row1);
+int64_t aurora_hip_band_staging_bytes(const aurora_hip_model* model);
+int aurora_hip_set_band_staging(aurora_hip_model* model, void* const send[2], void* const recv[2], int64_t staging_bytes);
+/* The partition and the attention plans themselves, as pure host functions (no model, no device work): what the handle
+ * uses internally, exposed for hosts that place data themselves and for tests (tests/test_partition.py compares them with
+ * numpy plans that are replayed against global attention).
+ * aurora_hip_band_partition: owned token rows [h0, h1) of `rank` at backbone stage `stage` (0 = finest) of an
+ * `n_stages`-stage U-net over a token grid res0 = (levels, latitude rows, longitude columns).
+ * aurora_hip_band_plan: the plan of one block flavour at one stage: `res` the stage's token grid, rows[2 r], rows[2 r + 1]
+ * the owned rows of rank r there.  Fills `info`; the arrays may be NULL (query sizes first): tok / grp
+ * [n_windows][win_tokens] (index into [owned rows | halo rows], -1 = padding or a position no owned query can see; grp is
+ * left untouched when has_groups == 0), send_idx_prev / _next: local indices of the owned rows sent to rank - 1 / + 1,
+ * in the receiver's halo order. */
+typedef struct aurora_hip_plan_info {
+  int32_t n_windows, win_tokens, n_own, n_halo, n_interior;   /* the first n_interior windows touch no halo row */
+  int32_t recv_offset[2], recv_count[2], send_count[2];       /* [0] previous rank, [1] next rank; offsets into the halo rows */
+  int32_t has_groups;
+} aurora_hip_plan_info;
+int aurora_hip_band_partition(int n_stages, const int32_t res0[3], const int32_t window[3], int world, int rank, int stage,
+                              int32_t* h0, int32_t* h1);
+int aurora_hip_band_plan(const int32_t res[3], const int32_t window[3], int shifted, int world, int rank,
+                         const int32_t* rows, aurora_hip_plan_info* info, int32_t* tok, uint8_t* grp,
+                         int32_t* send_idx_prev, int32_t* send_idx_next);
 
 /* Per-launch timing of the handle's own kernels: between _begin and _end every launch of a kernel kind whose bit is set
  * in kind_mask (bit i = entry i of the table _end returns: linear_bf16, linear_f32, window_attention_bf16, layernorm,
- * merge_ln, split_ln, patchify, perceiver_attention, assemble_tokens, unpatchify, copy2d, absmax, linear_layernorm_bf16) is
- * bracketed by a HIP event pair on the launch stream.  _end synchronises the device and fills `out` (capacity >= 13): launches, summed
+ * merge_ln, split_ln, patchify, perceiver_attention, assemble_tokens, unpatchify, copy2d, absmax, linear_layernorm_bf16,
+ * gather_rows) is bracketed by a HIP event pair on the launch stream.  _end synchronises the device and fills `out`
+ * (capacity >= 14): launches, summed
  * milliseconds and summed algorithmic work (FLOPs for the linears, bytes for the window attention) per kind.  This is
  * what bench.py's `roofline` is computed from.  An event pair keeps a launch from overlapping its neighbours. */
 typedef struct aurora_hip_profile_entry {

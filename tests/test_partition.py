@@ -187,3 +187,86 @@ def test_fused_layernorm_is_only_picked_when_its_tiles_fill_the_chip():
     assert not fused_ln_fills(16200, 256)         # 127 tiles: half a round
     assert lib.presplit_ok(2048, 1024) and lib.presplit_ok(512, 160)
     assert not lib.presplit_ok(80, 1024) and not lib.presplit_ok(512, 48) and not lib.presplit_ok(512, 176)
+
+
+# ---- the C++ twins inside libaurora_hip.so (csrc/band.hip): what the model handle really uses -----------------------
+def _c_rows(n_stages, res0, window, world):
+    import ctypes
+
+    from aurora_amd.engine import lib
+
+    L = lib.load()
+    i32 = lambda v: (ctypes.c_int32 * len(v))(*v)  # noqa: E731
+    out = []
+    for s in range(n_stages):
+        rows = []
+        for r in range(world):
+            h0, h1 = ctypes.c_int32(), ctypes.c_int32()
+            assert L.aurora_hip_band_partition(n_stages, i32(res0), i32(window), world, r, s, ctypes.byref(h0),
+                                               ctypes.byref(h1)) == 0, L.aurora_hip_last_error()
+            rows.append((h0.value, h1.value))
+        out.append(rows)
+    return out
+
+
+def _c_plan(res, window, shifted, world, rank, rows):
+    import ctypes
+
+    from aurora_amd.engine import lib
+
+    L = lib.load()
+    i32 = lambda v: (ctypes.c_int32 * len(v))(*v)  # noqa: E731
+    flat = i32([x for r in rows for x in r])
+    info = lib.HipPlanInfo()
+    args = (i32(res), i32(window), int(shifted), world, rank, flat, ctypes.byref(info))
+    assert L.aurora_hip_band_plan(*args, None, None, None, None) == 0, L.aurora_hip_last_error()
+    tok = np.empty((info.n_windows, info.win_tokens), np.int32)
+    grp = np.empty((info.n_windows, info.win_tokens), np.uint8)
+    sp, sn = np.empty(info.send_count[0], np.int32), np.empty(info.send_count[1], np.int32)
+    assert L.aurora_hip_band_plan(*args, tok.ctypes.data, grp.ctypes.data, sp.ctypes.data, sn.ctypes.data) == 0
+    return info, tok, (grp if info.has_groups else None), sp, sn
+
+
+@pytest.mark.parametrize("res0,window,n_stages,world", [
+    ((4, 180, 360), (2, 6, 12), 3, 8), ((4, 180, 360), (2, 6, 12), 3, 2), ((4, 150, 300), (2, 6, 12), 3, 4),
+    ((4, 45, 90), (2, 6, 12), 3, 3), ((4, 12, 8), (2, 4, 4), 2, 3), ((2, 9, 6), (2, 3, 3), 1, 3),
+])
+def test_c_partition_and_plans_equal_the_numpy_ones(res0, window, n_stages, world):
+    """csrc/band.hip (aurora_hip_band_partition / aurora_hip_band_plan) against partition.py, whose plans the tests above
+    replay against global attention: same owned rows; per rank the same windows, token / group tables (the C++ plan
+    lists the windows that touch no halo row first), receive slices and send lists."""
+    all_res, _ = geometry.stage_resolutions(res0, n_stages)
+    want_rows = partition.band_rows(all_res, window, world)
+    assert _c_rows(n_stages, res0, window, world) == [[tuple(r) for r in rows] for rows in want_rows]
+    for stage, res in enumerate(all_res):
+        for shifted in (False, True):
+            plans = partition.block_plans(tuple(res), tuple(window), shifted, tuple(want_rows[stage]))
+            for rank, p in enumerate(plans):
+                info, tok, grp, sp, sn = _c_plan(res, window, shifted, world, rank, want_rows[stage])
+                assert (info.n_own, info.n_halo, info.n_windows) == (p.n_own, p.n_halo, p.tok.shape[0])
+                halo = (p.tok >= p.n_own).any(axis=1)
+                order = np.concatenate([np.nonzero(~halo)[0], np.nonzero(halo)[0]])
+                assert info.n_interior == int((~halo).sum())
+                assert np.array_equal(tok, p.tok[order])
+                assert (grp is None) == (p.grp is None)
+                if grp is not None:
+                    assert np.array_equal(grp, p.grp[order])
+                for side, q, sent in ((0, rank - 1, sp), (1, rank + 1, sn)):
+                    if q in p.recv:
+                        assert (info.recv_offset[side], info.recv_count[side]) == p.recv[q]
+                    else:
+                        assert info.recv_count[side] == 0
+                    assert np.array_equal(sent, p.send.get(q, np.empty(0, np.int32)))
+                assert set(p.recv) <= {rank - 1, rank + 1} and set(p.send) <= {rank - 1, rank + 1}
+
+
+def test_c_partition_says_why_it_cannot_split():
+    import ctypes
+
+    from aurora_amd.engine import lib
+
+    L = lib.load()
+    i32 = lambda v: (ctypes.c_int32 * len(v))(*v)  # noqa: E731
+    h0, h1 = ctypes.c_int32(), ctypes.c_int32()
+    assert L.aurora_hip_band_partition(3, i32((4, 8, 16)), i32((2, 6, 12)), 8, 0, 0, ctypes.byref(h0), ctypes.byref(h1)) == -1
+    assert b"cannot split" in L.aurora_hip_last_error()
