@@ -16,7 +16,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "_lib" / "libaurora_hip.so"
-SOURCES = ("runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "embed.hip", "band.hip", "model.hip")
+SOURCES = ("runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "embed.hip", "band.hip", "model.hip", "step.hip")
 ARCH = "gfx950"
 
 
@@ -31,7 +31,7 @@ def is_stale() -> bool:
     if not LIB.exists():
         return True
     built = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "band.h", PKG.parent / "include" / "aurora_hip.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "band.h", CSRC / "model.h", PKG.parent / "include" / "aurora_hip.h"]
     return any(d.stat().st_mtime > built for d in deps)
 
 

@@ -1,105 +1,34 @@
-// One forecast step behind a C ABI: the model handle of libaurora_hip.so.
+// The model handle of libaurora_hip.so: creation, weights, tables.
 //
 // aurora_hip_create / _pack_weights / _finalize / _precompute / _set_time / _step / _destroy (include/aurora_hip.h) own
 // everything the reference's `Aurora.forward` (aurora/model/aurora.py:265-392) needs besides the input fields: the
 // configuration, the weights (fp32 masters + bf16 backbone copies, LoRA merged per roll-out phase), the tables that
 // depend on parameters / grid / levels only (AdaLN modulation, Fourier position / scale / level encodings, window
-// token tables), the workspace, and the SEQUENCE of kernel launches of a step -- encoder (encoder.py:198-366), 3D Swin
-// U-net (swin3d.py:884-936, 440-509), decoder (decoder.py:168-276) -- on a caller-supplied stream.  No torch, no Python:
-// any host language that can call C can run Aurora on an MI355X through these seven functions; aurora_amd's own
-// Python `Engine` uses them for the ERA5 model family.
+// token tables, a latitude band's halo plans), the workspace, and the SEQUENCE of kernel launches of a step (step.hip) on
+// a caller-supplied stream.  No torch, no Python: any host language that can call C can run Aurora on an MI355X through
+// these functions; aurora_amd's own Python `Engine` is a thin binding of them.
 //
-// Scope: the model family of BASELINE configs 1-4 (Aurora, AuroraPretrained, AuroraSmallPretrained,
-// Aurora12hPretrained, AuroraHighRes: any patch size / depths / history / LoRA mode, stabilised level aggregation,
-// batch > 1), one device, no latitude-band sharding.  The air-pollution and ocean-wave variants (level-conditioned
-// embeddings, feature combiners, second decoder Perceiver, NaN / angle hooks) and sharded steps are sequenced by the
-// Python engine over the same operator entry points.
+// Scope: every public model class -- Aurora, AuroraPretrained, AuroraSmallPretrained, Aurora12hPretrained, AuroraHighRes
+// (any patch size / depths / history / LoRA mode, stabilised level aggregation, batch > 1), AuroraAirPollution and
+// AuroraWave (level-conditioned embeddings / heads, dynamic and static inputs, feature combiners, difference prediction,
+// second decoder Perceiver, NaN / density / angle channels) -- on one device or as one latitude band of a forecast
+// sharded over several (aurora_hip_set_band).
 //
 // Host code only; every launch goes through the operator ABI of this same library.
-#include <math.h>
 #include <stdarg.h>
-#include <stdlib.h>
-#include <string.h>
 
 #include <algorithm>
-#include <array>
 #include <exception>
-#include <map>
-#include <memory>
-#include <string>
-#include <vector>
 
-#include "band.h"
-#include "common.h"
+#include "model.h"
 
-using namespace aurora;
+namespace aurora {
 
 namespace {
 
 constexpr double PI = 3.14159265358979323846;
 constexpr int LORA_RANK = 8;
-
-struct Fail {
-  int code;
-};
-#define REQUIRE(cond, ...)               \
-  do {                                   \
-    if (!(cond)) {                       \
-      ::aurora::set_error(__VA_ARGS__);  \
-      throw Fail{AURORA_E_ARG};          \
-    }                                    \
-  } while (0)
-inline void ok(int code) {
-  if (code != AURORA_OK) throw Fail{code};
-}
-inline void hip_ok(hipError_t e, const char* what) {
-  if (e != hipSuccess) {
-    set_error("%s: %s", what, hipGetErrorString(e));
-    throw Fail{AURORA_E_LAUNCH};
-  }
-}
-inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
-
-// ---- device memory -------------------------------------------------------------------------------
-struct DevBuf {   // owning, persistent
-  void* p = nullptr;
-  size_t bytes = 0;
-  DevBuf() = default;
-  explicit DevBuf(size_t n) : bytes(n) { hip_ok(hipMalloc(&p, n ? n : 16), "hipMalloc"); }
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; }
-  DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) {
-      if (p) (void)hipFree(p);
-      p = o.p; bytes = o.bytes; o.p = nullptr;
-    }
-    return *this;
-  }
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  float* f() const { return static_cast<float*>(p); }
-};
-
-// Workspace of a step: one slab, stack discipline (mark / release), so that the 48 blocks re-use the same few GB.
-// A step is first walked in `dry` mode (no launches) to learn its peak, the slab grows if needed, then it runs.
-struct Arena {
-  char* base = nullptr;
-  size_t cap = 0, top = 0, peak = 0;
-  void* take(size_t bytes) {
-    const size_t at = (top + 255) & ~size_t(255);
-    top = at + bytes;
-    if (top > peak) peak = top;
-    return base + at;   // (dry runs hand out addresses that are never dereferenced)
-  }
-  ~Arena() { if (base) (void)hipFree(base); }
-};
-
-struct Tensor {
-  DevBuf buf;
-  std::vector<int64_t> shape;
-  int64_t numel = 0;
-  float* f() const { return buf.f(); }
-};
+const char* const DYNAMIC_NAMES[6] = {"tod_cos", "tod_sin", "dow_cos", "dow_sin", "doy_cos", "doy_sin"};   // encoder.py:246
 
 // ---- host-side tables ----------------------------------------------------------------------------
 // Fourier features (aurora/model/fourier.py:45-92, 112-126): [sin(2 pi x / lambda_j) | cos(...)], lambda log-spaced,
@@ -200,128 +129,7 @@ void pos_scale_tables(const double* lat, const double* lon, int Hp, int Wp, int 
   fourier(SCALE, ra.data(), Lp, D, scale_out);
 }
 
-// ---- the model -----------------------------------------------------------------------------------
-struct Block {
-  std::string prefix;
-  int dim, stage, heads, hidden;
-  bool shifted;
-  const float *gain1, *shift1, *gain2, *shift2;     // AdaLN modulation (slices of `mod`)
-  const float *qkv_b, *proj_b, *fc1_b, *fc2_b;
-  const void *fc1_w, *fc2_w;                          // compute dtype
-};
-struct AttnSet { std::vector<DevBuf> own; std::vector<const void*> qkv, proj; };   // per block, compute dtype
-struct Resampler {
-  struct Layer {
-    const float *to_q, *to_kv, *to_out, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
-    const float *ln_k_w = nullptr, *ln_k_b = nullptr, *ln_q_w = nullptr, *ln_q_b = nullptr;
-    int inner, head_dim, hidden, dim;
-    float v_l1;
-    int f16_mode;   // fp32 GEMM mode of this layer's bounded linears: 2 (two fp16 terms) when weights / LN bounds allow
-    // the same weights in the fp16-pair layout, scaled by 2^6 (null where mode or shape rule it out): the two-term GEMMs
-    // then spend no VALU work on the weight operand, and none at all where the activations arrive split as well
-    const void *to_kv_s = nullptr, *to_out_s = nullptr, *fc1_s = nullptr, *fc2_s = nullptr;
-  };
-  std::vector<Layer> layers;
-  std::vector<DevBuf> own;
-};
-struct DevTables { DevBuf tok, grp; int n_windows = 0, n_tok = 0; bool has_grp = false; };
-
 }  // namespace
-
-struct aurora_hip_model {
-  // configuration
-  int D = 0, P = 0, Cl = 0, perceiver_heads = 0, n_stages = 0;
-  int enc_depths[4] = {0}, dec_depths[4] = {0}, enc_heads[4] = {0}, dec_heads[4] = {0}, window[3] = {0};
-  int enc_depth = 1, dec_depth = 1, max_history = 2, lora_steps = 40, lora_mode = 0;
-  bool stabilise = false, use_lora = false, autocast = false;
-  float ln_eps = 1e-5f;
-  double timestep_hours = 6;
-  std::vector<std::string> surf_vars, static_vars, atmos_vars;
-
-  // weights
-  std::map<std::string, Tensor> w;                // fp32 masters (aurora_hip_pack_weights / a packed file)
-  std::map<std::string, Tensor> w16;              // bf16-only entries of a packed file (shape kept, data bf16)
-  bool finalized = false;
-  std::vector<Block> blocks;
-  DevBuf mod, lead_emb, enc_q0;
-  std::vector<DevBuf> keep;                       // bf16 copies and other derived device arrays
-  std::map<int, AttnSet> attn_sets;               // LoRA key (-1 = base) -> merged qkv / proj weights
-  struct Merge { const void* w; const float *ln_w, *ln_b; };
-  struct Split { const void *w1, *w2; const float *ln_w, *ln_b; };
-  std::vector<Merge> merges;
-  std::vector<Split> splits;
-  Resampler enc_rs, dec_rs;
-
-  // grid / levels
-  bool have_grid = false;
-  int n_lat = 0, n_lon = 0, Hp = 0, Wp = 0, n_levels = 0;
-  DevBuf pos_scale, enc_bias, dec_queries, dec_q, stats;   // stats: loc | scale | inv per variable and level
-  std::vector<size_t> surf_stat_off, static_stat_off, atmos_stat_off;   // float offsets into `stats`: loc, then scale, inv
-  std::map<std::pair<int, int>, DevBuf> embed_w;           // (0 surf / 1 atmos, T) -> (D, Kpad) patch-embed GEMM weight
-  std::map<std::pair<int, int>, DevBuf> embed_ws;          // ... the same in the fp16-pair layout (scaled by 2^6), if eligible
-  std::map<std::pair<int, int>, float> embed_l1;           // ... its largest L1 row norm: |embedding| <= l1 * max|input| + |bias|
-  float enc_bias_max = 0.f;                                // max |atmospheric level bias| (precompute)
-  // surface MLP behind the surface patch embedding, for its guarded two-term chain (finalize): pre-split weights, the
-  // largest L1 row norm and |bias| of its first linear, max |embedding bias| + max |level encoding|
-  DevBuf surf_w0_s, surf_w2_s;
-  float surf_l1_0 = 0.f, surf_b0 = 0.f, surf_c = 0.f;
-  bool surf_chain = false;
-  DevBuf head_surf_w, head_surf_b, head_atmos_w, head_atmos_b;
-  std::map<std::pair<int, int>, DevTables> tables;         // (stage, shifted)
-  std::vector<Res> stage_res;
-  std::vector<std::array<int, 2>> merge_pad;               // (pad_h, pad_w) after each stage
-
-  // per step
-  DevBuf abs_enc, ctx_max;
-  int abs_B = 0;
-  struct Pinned { float* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; };
-  Pinned pinned[4];     // staging ring of aurora_hip_set_time: an upload never waits for the previous step
-  int pinned_next = 0;
-  ~aurora_hip_model() {
-    for (auto& t : timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
-    for (auto& e : event_pool) (void)hipEventDestroy(e);
-    for (auto& s : pinned) {
-      if (s.host) (void)hipHostFree(s.host);
-      if (s.done) (void)hipEventDestroy(s.done);
-    }
-  }
-  Arena arena;
-  bool dry = false;
-
-  // optional per-launch timing (aurora_hip_profile_begin / _end): HIP events on the launch stream
-  struct Timed { int kind; double work; hipEvent_t e0, e1; };
-  uint32_t profile_mask = 0;
-  std::vector<Timed> timed;
-  std::vector<hipEvent_t> event_pool;
-
-  const void* dt_ptr(const std::string& name);   // weight in the backbone compute dtype
-  const float* W(const std::string& name) const {
-    auto it = w.find(name);
-    REQUIRE(it != w.end(), "missing weight '%s'", name.c_str());
-    return it->second.f();
-  }
-  const Tensor& T_(const std::string& name) const {
-    auto it = w.find(name);
-    REQUIRE(it != w.end(), "missing weight '%s'", name.c_str());
-    return it->second;
-  }
-  bool has(const std::string& name) const { return w.count(name) != 0; }
-  int bb() const { return autocast ? AURORA_BF16 : AURORA_F32; }
-  size_t bbs() const { return autocast ? 2 : 4; }
-  int stage_dim(int s) const { return D << s; }
-};
-
-namespace {
-
-typedef aurora_hip_model Model;
-
-// Kernel kinds of the per-launch timing; `work` is the algorithmic work of a launch: FLOPs for the linears, bytes
-// (q, k, v read + o written once) for the window attention, 0 elsewhere.
-enum Kind { K_LINEAR_BF16, K_LINEAR_F32, K_WINDOW_ATTENTION, K_LAYERNORM, K_MERGE_LN, K_SPLIT_LN, K_PATCHIFY,
-            K_PERCEIVER_ATTENTION, K_ASSEMBLE, K_UNPATCHIFY, K_COPY2D, K_ABSMAX, K_LINEAR_LN, K_COUNT };
-const char* const KIND_NAMES[K_COUNT] = {"linear_bf16", "linear_f32", "window_attention_bf16", "layernorm", "merge_ln",
-                                         "split_ln", "patchify", "perceiver_attention", "assemble_tokens", "unpatchify",
-                                         "copy2d", "absmax", "linear_layernorm_bf16"};
 
 hipEvent_t take_event(Model& m) {
   if (!m.event_pool.empty()) {
@@ -334,52 +142,23 @@ hipEvent_t take_event(Model& m) {
   return e;
 }
 
-// Runs `fn` (one launch), bracketed by an event pair when this kind is being profiled.
-template <typename F>
-void timed(Model& m, void* stream, int kind, double work, F&& fn) {
-  if (m.dry) return;
-  const bool on = (m.profile_mask >> kind) & 1u;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (on) {
-    e0 = take_event(m);
-    e1 = take_event(m);
-    hip_ok(hipEventRecord(e0, as_stream(stream)), "hipEventRecord");
-  }
-  ok(fn());
-  if (on) {
-    hip_ok(hipEventRecord(e1, as_stream(stream)), "hipEventRecord");
-    m.timed.push_back({kind, work, e0, e1});
-  }
+int bounded_mode() {
+  static const int mode = getenv("AURORA_F32_GEMM") ? -1 : 2;
+  return mode;
 }
 
-// launches (skipped in a dry run)
-struct Launcher {
-  Model& m;
-  void* stream;
-  void linear(const void* A, int64_t lda, const void* Wt, int64_t ldw, const float* bias, void* C, int64_t ldc, int64_t M,
-              int N, int K, int dtype, int act = AURORA_ACT_NONE, void* C2 = nullptr, int64_t ldc2 = 0,
-              const float* res = nullptr, int64_t ldr = 0, int f32_gemm = -1, const float* guard = nullptr,
-              float limit = 0.f) {
-    timed(m, stream, dtype == AURORA_BF16 ? K_LINEAR_BF16 : K_LINEAR_F32, 2.0 * (double)M * N * K, [&] {
-      return aurora_hip_linear_ex(A, lda, Wt, ldw, bias, C, ldc, C2, ldc2, res, ldr, M, N, K, dtype, act, f32_gemm, guard,
-                                  limit, stream);
-    });
+std::string level_to_str(double level) {
+  const double value = round(level * 1000.0) / 1000.0;
+  char buf[64];
+  if (value == (double)(long long)value) snprintf(buf, sizeof buf, "%lld", (long long)value);
+  else {
+    snprintf(buf, sizeof buf, "%.3f", value);
+    std::string t(buf);
+    while (!t.empty() && t.back() == '0') t.pop_back();   // Python's str(float): shortest form of a 3-decimal value
+    for (char& ch : t) if (ch == '.') ch = '_';
+    return t;
   }
-  void layernorm(const void* y, int64_t ldy, const float* gain, const float* shift, const float* res, int64_t ldr,
-                 int64_t res_mod, float* out_f32, int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D, float eps,
-                 int dtype) {
-    timed(m, stream, K_LAYERNORM, 0.0, [&] {
-      return aurora_hip_layernorm(y, ldy, gain, shift, res, ldr, res_mod, out_f32, ldo, out_t, ldt, M, D, eps, dtype, stream);
-    });
-  }
-};
-
-void upload(void* dst, const void* src, size_t bytes) { hip_ok(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "upload"); }
-
-DevBuf to_device(const std::vector<float>& v) {
-  DevBuf b(v.size() * sizeof(float));
-  upload(b.p, v.data(), v.size() * sizeof(float));
-  return b;
+  return buf;
 }
 
 int lora_key(const Model& m, int step) {   // lora.py:105-129; -1 = no LoRA
@@ -388,6 +167,8 @@ int lora_key(const Model& m, int step) {   // lora.py:105-129; -1 = no LoRA
   if (m.lora_mode == 1) return step == 0 ? -1 : 0;      // from_second
   return step;                                          // all
 }
+
+namespace {
 
 // A backbone weight in the compute dtype: the fp32 master itself (autocast off), the bf16 entry of a packed file, or a
 // bf16 copy of the master made once.  `out_shape0` receives the leading dimension (hidden sizes are read off weights).
@@ -426,14 +207,6 @@ void build_blocks(Model& m) {
         m.blocks.push_back(b);
       }
     }
-}
-
-constexpr float F16_SAFE = 16384.0f;   // activations below this may take the two-term fp16 operand split
-// fp32 GEMM mode of the linears whose input is bounded (by construction or by the device-side guard): the two-term fp16
-// split, unless the user pinned a mode through AURORA_F32_GEMM
-int bounded_mode() {
-  static const int mode = getenv("AURORA_F32_GEMM") ? -1 : 2;
-  return mode;
 }
 
 Resampler pack_resampler(Model& m, const std::string& prefix, int depth, int heads) {
@@ -507,112 +280,7 @@ Resampler pack_resampler(Model& m, const std::string& prefix, int depth, int hea
 
 // What is known on the device about max |context| of a resampler: max|ctx| <= a * (*word) + c.  `pairs`: the context
 // buffer holds fp16 pairs iff *word < limit_kv (written so by a guarded two-term producer with that very guard), fp32 otherwise.
-struct CtxGuard { const float* word; float a, c, limit_kv; bool pairs; };
-
-// PerceiverResampler (perceiver.py:212-233) for all grid columns at once.  ctx: key j of column (b, l) at row
-// b*kv_bstride + j*kv_lstride + l.  First layer: latents (and so q) are shared by every column.  Returns (B*cols*Lq, D).
-float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, int64_t ctx_rows, int ctx_dim, const float* q0,
-                 const float* latents0, int B, int64_t cols, int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads,
-                 float eps, size_t& out_mark, const CtxGuard* cg = nullptr) {
-  const int64_t n_rows = (int64_t)B * cols * Lq;
-  // The context is as unbounded as the model inputs, so the linears that read it, or averages of its value projection,
-  // pick their operand split on the device: from max |ctx|, measured here, or from the bound the caller derived from a
-  // word it measured upstream (`cg`).
-  const float* ctx_max = cg ? cg->word : m.ctx_max.f();
-  const float g_a = cg ? cg->a : 1.0f, g_c = cg ? cg->c : 0.0f;
-  const bool ctx_pairs = cg && cg->pairs;
-  if (!cg) timed(m, L.stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(ctx, ctx_rows * ctx_dim, m.ctx_max.f(), L.stream); });
-  float* lat = nullptr;
-  for (size_t i = 0; i < rs.layers.size(); ++i) {
-    const auto& ly = rs.layers[i];
-    const int inner = ly.inner, Dd = ly.dim;
-    const size_t mark0 = m.arena.top;
-    // result of this layer first (it outlives the temporaries below; stack order)
-    float* y = (float*)m.arena.take((size_t)n_rows * Dd * 4);
-    const size_t after_y = m.arena.top;
-    float* kv = (float*)m.arena.take((size_t)ctx_rows * 2 * inner * 4);
-    // guarded linears with pre-split weights: the two-term launch runs iff the guard holds, the three-term one (fp32
-    // weights) iff it does not
-    auto guarded = [&](const float* A, int64_t lda, const float* Wf, const void* Ws, float* C_, int64_t ldc, int64_t M_, int N_,
-                       int K_, float limit, bool a_pairs = false) {
-      if (Ws) {
-        L.linear(A, lda, Ws, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0,
-                 2 | AURORA_F32_W_SPLIT | (a_pairs ? AURORA_F32_A_SPLIT : 0), ctx_max, limit);
-        L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, 1, ctx_max, limit);
-      } else if (ly.f16_mode == 2) {   // one guarded call: the device word picks the two- or the three-term kernel
-        L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, 2, ctx_max, limit);
-      } else {
-        // a pinned mode (AURORA_F32_GEMM) or weights outside the two-term range: NO guard -- a mode-1 launch that carries a
-        // guard is the three-term half of a guarded pair and runs only if the guard FAILS (include/aurora_hip.h)
-        L.linear(A, lda, Wf, K_, nullptr, C_, ldc, M_, N_, K_, AURORA_F32, 0, nullptr, 0, nullptr, 0, ly.f16_mode, nullptr, 0.f);
-      }
-    };
-    // |ctx| <= g_a * word + g_c < F16_SAFE  <=>  word < (F16_SAFE - g_c) / g_a; a context in pairs comes with its own limit
-    REQUIRE(!ctx_pairs || ly.to_kv_s, "resampler: a pair-layout context needs pre-split to_kv weights");
-    guarded(ctx, ctx_dim, ly.to_kv, ly.to_kv_s, kv, 2 * inner, ctx_rows, 2 * inner, ctx_dim,
-            ctx_pairs ? cg->limit_kv : (F16_SAFE - g_c) / g_a, ctx_pairs);
-    if (ly.ln_k_w)   // LayerNorm over the K half, in place (perceiver.py:144-147)
-      L.layernorm(kv, 2 * inner, ly.ln_k_w, ly.ln_k_b, nullptr, 0, 0, kv, 2 * inner, nullptr, 0, ctx_rows, inner, 1e-5f,
-                  AURORA_F32);
-    const float* q = q0;
-    int64_t q_stride = 0;
-    if (i > 0) {
-      float* qb = (float*)m.arena.take((size_t)n_rows * inner * 4);
-      L.linear(lat, Dd, ly.to_q, Dd, nullptr, qb, inner, n_rows, inner, Dd, AURORA_F32);
-      if (ly.ln_q_w) L.layernorm(qb, inner, ly.ln_q_w, ly.ln_q_b, nullptr, 0, 0, qb, inner, nullptr, 0, n_rows, inner, 1e-5f, AURORA_F32);
-      q = qb;
-      q_stride = Lq;
-    }
-    float* att = (float*)m.arena.take((size_t)n_rows * inner * 4);
-    // |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit.  With pre-split to_out
-    // weights the attention writes fp16 pairs iff that guard holds, and to_out multiplies them without splitting anything.
-    const float lim_out = (F16_SAFE / ly.v_l1 - g_c) / g_a;
-    const bool att_pairs = ly.to_out_s != nullptr && inner % 32 == 0;
-    timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] {
-      return aurora_hip_perceiver_attention_ex(q, q_stride, kv, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim,
-                                               AURORA_F32, att_pairs ? ctx_max : nullptr, lim_out, L.stream);
-    });
-    float* o = (float*)m.arena.take((size_t)n_rows * Dd * 4);
-    guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, lim_out, att_pairs);
-    // The MLP in the fp16-pair layout end to end: the LayerNorm writes its result already split (and ONLY split), fc1
-    // reads that and writes its GELU'd result split, fc2 reads that -- neither GEMM splits anything -- and the LayerNorm
-    // behind the MLP takes the split array as its residual.
-    const bool pairs = ly.fc1_s && ly.fc2_s && Dd % 32 == 0;
-    float* lat1 = (float*)m.arena.take((size_t)n_rows * Dd * 4);   // fp32 values, or their fp16 pairs
-    {
-      const float* res_ = i == 0 ? latents0 : lat;
-      const int64_t mod_ = i == 0 ? Lq : 0;
-      if (pairs)
-        timed(m, L.stream, K_LAYERNORM, 0.0, [&] {
-          return aurora_hip_layernorm_split(o, Dd, ly.ln1_w, ly.ln1_b, res_, Dd, mod_, 0, nullptr, 0, lat1, Dd, n_rows, Dd, eps,
-                                            L.stream);
-        });
-      else L.layernorm(o, Dd, ly.ln1_w, ly.ln1_b, res_, Dd, mod_, lat1, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
-    }
-    float* hid = (float*)m.arena.take((size_t)n_rows * ly.hidden * 4);
-    // fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU: bounded whatever the inputs are
-    if (pairs) {
-      const int all = 2 | AURORA_F32_A_SPLIT | AURORA_F32_W_SPLIT;
-      L.linear(lat1, Dd, ly.fc1_s, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
-               nullptr, 0, all | AURORA_F32_C_SPLIT);
-      L.linear(hid, ly.hidden, ly.fc2_s, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0, all);
-    } else {
-      L.linear(lat1, Dd, ly.fc1_w, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
-               nullptr, 0, ly.f16_mode);
-      L.linear(hid, ly.hidden, ly.fc2_w, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0,
-               ly.f16_mode);
-    }
-    if (pairs)
-      timed(m, L.stream, K_LAYERNORM, 0.0, [&] {
-        return aurora_hip_layernorm_split(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, 1, y, Dd, nullptr, 0, n_rows, Dd, eps, L.stream);
-      });
-    else L.layernorm(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, y, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
-    m.arena.top = after_y;            // temporaries of this layer are dead (a previous layer's result stays below y)
-    lat = y;
-    if (i == 0) out_mark = mark0;
-  }
-  return lat;
-}
+}  // namespace
 
 const DevTables& tables_for(Model& m, int stage, bool shifted) {
   auto key = std::make_pair(stage, (int)shifted);
@@ -694,377 +362,194 @@ const AttnSet& attn_weights(Model& m, int key, void* stream) {
   return m.attn_sets.emplace(key, std::move(set)).first->second;
 }
 
-// (D, Kpad) GEMM weight of a LevelPatchEmbed for the model's variable order and T history steps (patchembed.py:100-115):
-// per-variable (D, 1, Tmax, P, P) weights cut to T and laid out (v, t, i, j) along K, zero-padded to a multiple of 32.
-const float* embed_weight(Model& m, int kind, int T, int& K, int& Kpad) {
-  const std::vector<std::string>* names[2] = {nullptr, &m.atmos_vars};
-  std::vector<std::string> surf_all = m.surf_vars;
-  surf_all.insert(surf_all.end(), m.static_vars.begin(), m.static_vars.end());
-  names[0] = &surf_all;
-  const std::string prefix = kind == 0 ? "encoder.surf_token_embeds.weights." : "encoder.atmos_token_embeds.weights.";
-  const int V = (int)names[kind]->size(), PP = m.P * m.P;
-  K = V * T * PP;
-  Kpad = round_up(K, 32);
-  auto key = std::make_pair(kind, T);
-  auto it = m.embed_w.find(key);
-  if (it != m.embed_w.end()) return it->second.f();
-  std::vector<float> host((size_t)m.D * Kpad, 0.f);
-  for (int v = 0; v < V; ++v) {
-    const Tensor& t = m.T_(prefix + (*names[kind])[v]);   // (D, 1, Tmax, P, P)
-    REQUIRE(t.shape.size() == 5 && t.shape[0] == m.D && t.shape[2] >= T && t.shape[3] == m.P, "bad patch-embed weight shape");
-    const int64_t Tmax = t.shape[2];
-    std::vector<float> wv((size_t)t.numel);
-    hip_ok(hipMemcpy(wv.data(), t.f(), wv.size() * 4, hipMemcpyDeviceToHost), "download");
-    for (int d = 0; d < m.D; ++d)
-      for (int tt = 0; tt < T; ++tt)
-        memcpy(&host[(size_t)d * Kpad + ((size_t)v * T + tt) * PP], &wv[((size_t)d * Tmax + tt) * PP], PP * sizeof(float));
+// The attention plan of one block flavour of this rank's band, on the device.
+const DevPlan& plan_for(Model& m, int stage, bool shifted) {
+  auto key = std::make_pair(stage, (int)shifted);
+  auto it = m.plans.find(key);
+  if (it == m.plans.end()) {
+    BandPlan p;
+    if (!band_plan(m.stage_res[stage], m.window, shifted, m.band.rank, m.rows[stage], p)) throw Fail{AURORA_E_ARG};
+    REQUIRE(p.n_tok <= 144, "windows of more than 144 tokens are not supported");
+    DevPlan d;
+    d.n_windows = p.n_windows; d.n_tok = p.n_tok; d.n_own = p.n_own; d.n_halo = p.n_halo; d.n_interior = p.n_interior;
+    d.tok = DevBuf(p.tok.size() * 4);
+    upload(d.tok.p, p.tok.data(), p.tok.size() * 4);
+    d.has_grp = !p.grp.empty();
+    if (d.has_grp) {
+      d.grp = DevBuf(p.grp.size());
+      upload(d.grp.p, p.grp.data(), p.grp.size());
+    }
+    for (int side = 0; side < 2; ++side) {
+      d.recv_off[side] = p.recv_off[side]; d.recv_cnt[side] = p.recv_cnt[side];
+      d.send_cnt[side] = (int)p.send_idx[side].size();
+      if (d.send_cnt[side] > 0) {
+        d.send_idx[side] = DevBuf(p.send_idx[side].size() * 4);
+        upload(d.send_idx[side].p, p.send_idx[side].data(), p.send_idx[side].size() * 4);
+      }
+    }
+    it = m.plans.emplace(key, std::move(d)).first;
+  }
+  return it->second;
+}
+
+// (groups, D, Kpad) GEMM weight of a LevelPatchEmbed for the channels that are present and T history steps
+// (patchembed.py:100-115): per-variable (D, 1, Tmax, P, P) weights cut to T and laid out (v, t, i, j) along K, zero-padded
+// to a multiple of 32.  Level-conditioned models (levelcond.py:36-69) hold one such weight per pressure level.
+const EmbedPack& embed_pack(Model& m, int kind, int T, const std::vector<char>& present) {
+  const std::vector<Channel>& chans = kind == 0 ? m.surf_channels : m.atmos_channels;
+  int64_t mask = 0, mask_hi = 0;
+  REQUIRE(chans.size() <= 126, "more than 126 input channels");
+  for (size_t i = 0; i < chans.size(); ++i)
+    if (present[i]) (i < 63 ? mask : mask_hi) |= (int64_t)1 << (i % 63);
+  const std::array<int64_t, 3> key{(int64_t)kind * 1024 + T, mask, mask_hi};
+  auto it = m.embed_packs.find(key);
+  if (it != m.embed_packs.end()) return it->second;
+  EmbedPack pk;
+  for (size_t i = 0; i < chans.size(); ++i)
+    if (present[i]) pk.channels.push_back((int)i);
+  REQUIRE(!pk.channels.empty(), "no %s variable given", kind == 0 ? "surface-level" : "atmospheric");
+  const bool per_level = kind == 1 && !m.level_condition.empty();
+  pk.groups = per_level ? m.n_levels : 1;
+  const int V = (int)pk.channels.size(), PP = m.P * m.P;
+  pk.K = V * T * PP;
+  pk.Kpad = round_up(pk.K, 32);
+  std::vector<float> host((size_t)pk.groups * m.D * pk.Kpad, 0.f);
+  for (int g = 0; g < pk.groups; ++g) {
+    const std::string prefix = kind == 0 ? "encoder.surf_token_embeds.weights."
+                               : per_level ? "encoder.atmos_token_embeds.layers." + level_to_str(m.levels[g]) + ".weights."
+                                           : "encoder.atmos_token_embeds.weights.";
+    for (int v = 0; v < V; ++v) {
+      const Tensor& t = m.T_(prefix + chans[pk.channels[v]].name);   // (D, 1, Tmax, P, P)
+      REQUIRE(t.shape.size() == 5 && t.shape[0] == m.D && t.shape[2] >= T && t.shape[3] == m.P, "bad patch-embed weight shape");
+      const int64_t Tmax = t.shape[2];
+      const std::vector<float> wv = to_host(t);
+      for (int d = 0; d < m.D; ++d)
+        for (int tt = 0; tt < T; ++tt)
+          memcpy(&host[((size_t)g * m.D + d) * pk.Kpad + ((size_t)v * T + tt) * PP], &wv[((size_t)d * Tmax + tt) * PP], PP * sizeof(float));
+    }
   }
   float l1 = 1e-6f, wmax = 0.f;
-  for (int d = 0; d < m.D; ++d) {
+  for (size_t r = 0; r < (size_t)pk.groups * m.D; ++r) {
     float sum = 0.f;
-    for (int k = 0; k < Kpad; ++k) {
-      const float a = fabsf(host[(size_t)d * Kpad + k]);
+    for (int k = 0; k < pk.Kpad; ++k) {
+      const float a = fabsf(host[r * pk.Kpad + k]);
       sum += a;
       wmax = std::max(wmax, a);
     }
     l1 = std::max(l1, sum);
   }
-  DevBuf b = to_device(host);
-  m.embed_l1[key] = l1;
+  pk.l1 = l1;
+  pk.w = to_device(host);
   // the fp16-pair form for the guarded two-term kernel (the raw, normalised inputs are bounded only by the guard)
-  if (bounded_mode() == 2 && wmax < 1000.f && m.D % 256 == 0 && Kpad >= 96) {
-    DevBuf sp((size_t)m.D * Kpad * 4);
-    if (aurora_hip_split_f16(b.f(), Kpad, sp.p, Kpad, m.D, Kpad, 64.0f, nullptr) != AURORA_OK)
+  if (bounded_mode() == 2 && wmax < 1000.f && m.D % 256 == 0 && pk.Kpad >= 96) {
+    pk.ws = DevBuf(host.size() * 4);
+    if (aurora_hip_split_f16(pk.w.f(), pk.Kpad, pk.ws.p, pk.Kpad, (int64_t)pk.groups * m.D, pk.Kpad, 64.0f, nullptr) != AURORA_OK)
       throw std::runtime_error(aurora_hip_last_error());
     hip_ok(hipDeviceSynchronize(), "split embed weights");
-    m.embed_ws.emplace(key, std::move(sp));
   }
-  return m.embed_w.emplace(key, std::move(b)).first->second.f();
+  return m.embed_packs.emplace(key, std::move(pk)).first->second;
 }
 
+namespace {
 
-struct StepIO {
-  const aurora_hip_step_io* io;
-  int B, T, H, W;
-};
+bool contains(const std::vector<std::string>& v, const std::string& s) { return std::find(v.begin(), v.end(), s) != v.end(); }
 
-float* run_step(Model& m, const StepIO& s, void* stream) {
-  Launcher L{m, stream};
-  Arena& A = m.arena;
-  A.top = 0;
-  const aurora_hip_step_io& io = *s.io;
-  const int B = s.B, T = s.T, P = m.P, D = m.D, Hp = m.Hp, Wp = m.Wp, Cl = m.Cl, C = m.n_levels;
-  const int64_t Lp = (int64_t)Hp * Wp;          // patches per level
-  const int PP = P * P;
-  const int n_surf = (int)m.surf_vars.size(), n_static = (int)m.static_vars.size(), n_atmos = (int)m.atmos_vars.size();
-  const float* st = m.stats.f();
-
-  // ================= encoder (encoder.py:198-366) =================
-  const size_t enc_mark = A.top;
-  float* x_f = (float*)A.take((size_t)B * Cl * Lp * D * 4);                      // residual stream of stage 0 (fp32)
-  void* x_b = m.autocast ? A.take((size_t)B * Cl * Lp * D * 2) : nullptr;        // bf16 shadow (GEMM operand)
-  const size_t after_x = A.top;
-  {
-    // ---- surface level: normalise + unfold, patch embedding, MLP, LayerNorm ----
-    int K_s, Kpad_s;
-    const float* w_s = embed_weight(m, 0, T, K_s, Kpad_s);
-    float* A_s = (float*)A.take((size_t)B * Lp * Kpad_s * 4);
-    std::vector<aurora_patch_var> descs;
-    for (int v = 0; v < n_surf; ++v)
-      descs.push_back({io.surf[v], io.surf_strides[0], io.surf_strides[1], 0, io.surf_strides[2], io.surf_strides[3],
-                       st + m.surf_stat_off[v], st + m.surf_stat_off[v] + 2, 0, 0.f, 0.f, 0.f});
-    for (int v = 0; v < n_static; ++v)
-      descs.push_back({io.stat[v], 0, 0, 0, io.static_strides[0], io.static_strides[1], st + m.static_stat_off[v],
-                       st + m.static_stat_off[v] + 2, 0, 0.f, 0.f, 0.f});
-    for (size_t i = 0; i < descs.size(); i += 32)
-      timed(m, stream, K_PATCHIFY, 0.0, [&] {
-        return aurora_hip_patchify(descs.data() + i, (int)std::min<size_t>(32, descs.size() - i), A_s, Kpad_s, (int)i * T * PP,
-                                   K_s, B, T, 1, Hp, Wp, P, AURORA_F32, stream);
-      });
-    float* xs0 = (float*)A.take((size_t)B * Lp * D * 4);
-    const int hid_s = (int)m.T_("encoder.surf_mlp.net.0.weight").shape[0];
-    float* hid = (float*)A.take((size_t)B * Lp * hid_s * 4);
-    float* y = (float*)A.take((size_t)B * Lp * D * 4);
-    // Guarded like the atmospheric chain: max |normalised input| once, then every linear takes two fp16 terms iff the
-    // bound that word implies for ITS activation operand is inside fp16's range -- embedding: the input itself; first
-    // MLP linear: |xs0| <= l1_e * w + c; second: |GELU(h)| <= |h| <= l1_0 * (l1_e * w + c) + |b0| -- else three bf16 terms.
-    const auto skey = std::make_pair(0, T);
-    const void* w_s_s = m.embed_ws.count(skey) ? m.embed_ws.at(skey).p : nullptr;
-    if (m.surf_chain && w_s_s) {
-      float* word = m.ctx_max.f() + 2;
-      timed(m, stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(A_s, (int64_t)B * Lp * Kpad_s, word, stream); });
-      const float l1e = m.embed_l1.at(skey);
-      const float lim_e = F16_SAFE, lim_0 = (F16_SAFE - m.surf_c) / l1e, lim_2 = ((F16_SAFE - m.surf_b0) / m.surf_l1_0 - m.surf_c) / l1e;
-      auto pair = [&](const float* a, int64_t lda, const float* wf, const void* ws, const float* bias, float* c, int64_t ldc, int N_,
-                      int K_, int act, const float* res, float limit) {
-        L.linear(a, lda, ws, K_, bias, c, ldc, B * Lp, N_, K_, AURORA_F32, act, nullptr, 0, res, 0, 2 | AURORA_F32_W_SPLIT, word, limit);
-        L.linear(a, lda, wf, K_, bias, c, ldc, B * Lp, N_, K_, AURORA_F32, act, nullptr, 0, res, 0, 1, word, limit);
-      };
-      pair(A_s, Kpad_s, w_s, w_s_s, m.W("encoder.surf_token_embeds.bias"), xs0, D, D, Kpad_s, 0, m.W("encoder.surf_level_encoding"), lim_e);
-      pair(xs0, D, m.W("encoder.surf_mlp.net.0.weight"), m.surf_w0_s.p, m.W("encoder.surf_mlp.net.0.bias"), hid, hid_s, hid_s, D,
-           AURORA_ACT_GELU, nullptr, lim_0);
-      pair(hid, hid_s, m.W("encoder.surf_mlp.net.2.weight"), m.surf_w2_s.p, m.W("encoder.surf_mlp.net.2.bias"), y, D, D, hid_s, 0,
-           nullptr, lim_2);
-    } else {
-      L.linear(A_s, Kpad_s, w_s, Kpad_s, m.W("encoder.surf_token_embeds.bias"), xs0, D, B * Lp, D, Kpad_s, AURORA_F32, 0, nullptr,
-               0, m.W("encoder.surf_level_encoding"), 0);
-      L.linear(xs0, D, m.W("encoder.surf_mlp.net.0.weight"), D, m.W("encoder.surf_mlp.net.0.bias"), hid, hid_s, B * Lp, hid_s, D,
-               AURORA_F32, AURORA_ACT_GELU);
-      L.linear(hid, hid_s, m.W("encoder.surf_mlp.net.2.weight"), hid_s, m.W("encoder.surf_mlp.net.2.bias"), y, D, B * Lp, D, hid_s,
-               AURORA_F32);
-    }
-    L.layernorm(y, D, m.W("encoder.surf_norm.weight"), m.W("encoder.surf_norm.bias"), xs0, D, 0, y, D, nullptr, 0, B * Lp, D, 1e-5f,
-                AURORA_F32);   // xs0 + LN(MLP(xs0)), in place
-    const float* xs1 = y;
-
-    // ---- atmospheric levels ----
-    int K_a, Kpad_a;
-    const float* w_a = embed_weight(m, 1, T, K_a, Kpad_a);
-    float* A_a = (float*)A.take((size_t)C * B * Lp * Kpad_a * 4);
-    std::vector<aurora_patch_var> adescs;
-    for (int v = 0; v < n_atmos; ++v)
-      adescs.push_back({io.atmos[v], io.atmos_strides[0], io.atmos_strides[1], io.atmos_strides[2], io.atmos_strides[3],
-                        io.atmos_strides[4], st + m.atmos_stat_off[v], st + m.atmos_stat_off[v] + 2 * C, 0, 0.f, 0.f, 0.f});
-    for (size_t i = 0; i < adescs.size(); i += 32)
-      timed(m, stream, K_PATCHIFY, 0.0, [&] {
-        return aurora_hip_patchify(adescs.data() + i, (int)std::min<size_t>(32, adescs.size() - i), A_a, Kpad_a,
-                                   (int)i * T * PP, K_a, B, T, C, Hp, Wp, P, AURORA_F32, stream);
-      });
-    float* xa = (float*)A.take((size_t)C * B * Lp * D * 4);
-    const int64_t R = (int64_t)B * Lp;
-    // The patch embedding and the level aggregation's to_kv as one guarded chain: max |normalised input| is measured
-    // once (a third of the bytes of the embeddings the resampler would otherwise scan), and if it is inside fp16's range
-    // -- together with the bound it implies for the embeddings, |x| <= l1 * max|input| + max|bias| -- the embedding runs
-    // on two fp16 terms and writes fp16 PAIRS, which to_kv multiplies without splitting anything; otherwise both run on
-    // three bf16 terms over fp32 buffers.  One word and one limit decide format and kernels together.
-    const auto ekey = std::make_pair(1, T);
-    const void* w_a_s = m.embed_ws.count(ekey) ? m.embed_ws.at(ekey).p : nullptr;
-    bool chain = w_a_s != nullptr;
-    for (const auto& ly : m.enc_rs.layers) chain = chain && ly.f16_mode == 2 && ly.to_kv_s != nullptr;
-    CtxGuard cg{};
-    if (chain) {
-      float* word = m.ctx_max.f() + 1;
-      timed(m, stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(A_a, (int64_t)C * R * Kpad_a, word, stream); });
-      const float l1 = m.embed_l1.at(ekey), cb = m.enc_bias_max;
-      cg = CtxGuard{word, l1, cb, std::min(F16_SAFE, (F16_SAFE - cb) / l1), true};
-    }
-    for (int c = 0; c < C; ++c) {
-      const float* a_c = A_a + (size_t)c * R * Kpad_a;
-      const float* b_c = m.enc_bias.f() + (size_t)c * D;
-      float* x_c = xa + (size_t)c * R * D;
-      if (chain) {
-        L.linear(a_c, Kpad_a, w_a_s, Kpad_a, b_c, x_c, D, R, D, Kpad_a, AURORA_F32, 0, nullptr, 0, nullptr, 0,
-                 2 | AURORA_F32_W_SPLIT | AURORA_F32_C_SPLIT, cg.word, cg.limit_kv);
-        L.linear(a_c, Kpad_a, w_a, Kpad_a, b_c, x_c, D, R, D, Kpad_a, AURORA_F32, 0, nullptr, 0, nullptr, 0, 1, cg.word, cg.limit_kv);
-      } else {
-        L.linear(a_c, Kpad_a, w_a, Kpad_a, b_c, x_c, D, R, D, Kpad_a, AURORA_F32);
+// Input channels of the two patch embeddings and the decoder's heads / outputs, from the variant keywords
+// (encoder.py:226-303; aurora.py:733-742, 892-932; decoder.py:214-263).
+void build_channels(Model& m) {
+  m.surf_channels.clear(); m.atmos_channels.clear(); m.surf_heads.clear(); m.surf_out.clear(); m.atmos_heads.clear();
+  if (m.variant == 2) {
+    // ocean wave: the caller supplies the variables themselves; the model sees value (NaN -> 0) + density channels and
+    // sin / cos of the directions -- the variables that stay, then the appended channels (aurora.py:892-912)
+    std::vector<Channel> kept, appended;
+    for (size_t i = 0; i < m.surf_inputs.size(); ++i) {
+      const std::string& k = m.surf_inputs[i];
+      const bool dens = contains(m.density_vars, k), ang = contains(m.angle_vars, k);
+      if (!ang) kept.push_back({k, SRC_SURF, (int)i, dens ? 4 : 0});
+      if (dens) appended.push_back({k + "_density", SRC_SURF, (int)i, 3});
+      if (ang) {
+        appended.push_back({k + "_sin", SRC_SURF, (int)i, 5});
+        appended.push_back({k + "_cos", SRC_SURF, (int)i, 6});
       }
     }
-
-    // ---- level aggregation (Perceiver resampler over the level axis) ----
-    size_t rs_mark = 0;
-    float* lat = resampler(m, L, m.enc_rs, xa, (int64_t)C * R, D, m.enc_q0.f(), m.W("encoder.atmos_latents"), B, Lp, Lp, R,
-                           Cl - 1, C, m.perceiver_heads, m.ln_eps, rs_mark, chain ? &cg : nullptr);
-
-    // ---- assemble tokens + position / scale / time embeddings ----
-    float* time_emb = (float*)A.take((size_t)B * D * 4);
-    L.linear(m.abs_enc.f(), D, m.W("encoder.absolute_time_embed.weight"), D, m.W("encoder.absolute_time_embed.bias"), time_emb, D,
-             B, D, D, AURORA_F32, 0, nullptr, 0, m.lead_emb.f(), 0);
-    timed(m, stream, K_ASSEMBLE, 0.0, [&] { return aurora_hip_assemble_tokens(xs1, lat, m.pos_scale.f(), time_emb, x_f, x_b, B, Cl, Lp, D,
-                                    m.autocast ? AURORA_BF16 : AURORA_F32, stream); });
-  }
-  A.top = after_x;   // every encoder temporary is dead
-  (void)enc_mark;
-
-  // ================= backbone (swin3d.py:884-936) =================
-  const int bb = m.bb();
-  const size_t es = m.bbs();
-  const bool bf = m.autocast;
-  const AttnSet& aw = attn_weights(m, lora_key(m, io.rollout_step), stream);
-  const int n = m.n_stages;
-  std::vector<float*> skips;
-  size_t bi = 0;
-  // x_cat (B*L0, 2*D0): decoder output | encoder stage-0 output -- allocated now so that it survives the stack
-  const int64_t L0 = (int64_t)Cl * Lp;
-  float* x_cat = (float*)A.take((size_t)B * L0 * 2 * D * 4);
-
-  auto run_blocks = [&](int count, float* xf, void* xb, int stage, float* final_out, int64_t final_ld) {
-    const Res res = m.stage_res[stage];
-    const int64_t Ls = (int64_t)res.c * res.h * res.w, M = (int64_t)B * Ls;
-    for (int k = 0; k < count; ++k, ++bi) {
-      const Block& blk = m.blocks[bi];
-      const int dim = blk.dim;
-      const void* a_in = bf ? xb : (const void*)xf;
-      const size_t mark = A.top;
-      void* qkv = A.take((size_t)M * 3 * dim * es);
-      L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
-      const DevTables& tb = tables_for(m, stage, blk.shifted);
-      void* ao = A.take((size_t)M * dim * es);
-      // algorithmic bytes: q, k, v read + o written once over the (padded) windows
-      timed(m, stream, K_WINDOW_ATTENTION, 4.0 * B * tb.n_windows * tb.n_tok * dim * es, [&] {
-        return aurora_hip_window_attention(qkv, blk.qkv_b, ao, (const int32_t*)tb.tok.p,
-                                           tb.has_grp ? (const uint8_t*)tb.grp.p : nullptr, B, Ls, Ls, dim, blk.heads,
-                                           tb.n_windows, tb.n_tok, bb, stream);
-      });
-      // D = 512 under autocast: the linear, its AdaLN and the residual add are ONE launch (a workgroup owns whole rows)
-      // AURORA_FUSE_LN: 0 never, 1 (default) by the fill rule below, 2 always (tests: read per step, not cached)
-      const char* fuse_e = getenv("AURORA_FUSE_LN");
-      const int fuse_env = fuse_e ? atoi(fuse_e) : 1;
-      // (a row-owning tile is 128 rows: only when the launch fills its rounds of one tile per CU -- a latitude band's
-      // 270 tiles on 256 CUs would take two rounds for the work of 1.05)
-      const int64_t ln_tiles = (M + 127) / 128, cus = device_cus();
-      const bool fills = (double)ln_tiles >= 0.85 * (double)(((ln_tiles + cus - 1) / cus) * cus);
-      const bool fuse = bf && dim == 512 && (fuse_env == 2 || (fuse_env == 1 && fills));
-      auto fused = [&](const void* a, const void* w, const float* bias, int K_, const float* gain, const float* shift, float* xo,
-                       int64_t ldo, void* xbo) {
-        timed(m, stream, K_LINEAR_LN, 2.0 * (double)M * dim * K_, [&] {
-          return aurora_hip_linear_layernorm(a, K_, w, K_, bias, gain, shift, xf, dim, xo, ldo, xbo, dim, M, dim, K_, 1e-5f, stream);
-        });
-      };
-      if (fuse) {
-        fused(ao, aw.proj[bi], blk.proj_b, dim, blk.gain1, blk.shift1, xf, dim, xb);
-      } else {
-        void* y = A.take((size_t)M * dim * es);
-        L.linear(ao, dim, aw.proj[bi], dim, blk.proj_b, y, dim, M, dim, dim, bb);
-        L.layernorm(y, dim, blk.gain1, blk.shift1, xf, dim, 0, xf, dim, xb, dim, M, dim, 1e-5f, bb);
-      }
-      A.top = mark;
-      void* hid = A.take((size_t)M * blk.hidden * es);
-      L.linear(a_in, dim, blk.fc1_w, dim, blk.fc1_b, hid, blk.hidden, M, blk.hidden, dim, bb, AURORA_ACT_GELU);
-      const bool last = final_out != nullptr && k == count - 1;
-      if (fuse) {
-        fused(hid, blk.fc2_w, blk.fc2_b, blk.hidden, blk.gain2, blk.shift2, last ? final_out : xf, last ? final_ld : dim,
-              last ? nullptr : xb);
-      } else {
-        void* y2 = A.take((size_t)M * dim * es);
-        L.linear(hid, blk.hidden, blk.fc2_w, blk.hidden, blk.fc2_b, y2, dim, M, dim, blk.hidden, bb);
-        L.layernorm(y2, dim, blk.gain2, blk.shift2, xf, dim, 0, last ? final_out : xf, last ? final_ld : dim, last ? nullptr : xb,
-                    dim, M, dim, 1e-5f, bb);
-      }
-      A.top = mark;
+    for (const auto& c : kept) { m.surf_channels.push_back(c); m.surf_out.push_back(c.name); }
+    for (const auto& c : appended) m.surf_channels.push_back(c);
+    for (const auto& c : m.surf_channels) m.surf_heads.push_back(c.name);
+    for (const auto& a : m.angle_vars)   // predicted directions follow the variables that stayed (aurora.py:914-932)
+      if (contains(m.surf_heads, a + "_sin") && !contains(m.surf_out, a)) m.surf_out.push_back(a);
+    for (const auto& c : m.surf_channels)
+      REQUIRE(contains(m.surf_vars, c.name), "ocean wave: channel '%s' is not among the model's surf_vars", c.name.c_str());
+  } else {
+    for (size_t i = 0; i < m.surf_inputs.size(); ++i) {
+      const std::string& k = m.surf_inputs[i];
+      const int tr = contains(m.pos_surf, k) ? (m.variant == 1 ? 2 : 1) : 0;   // clamp, or clamp + log feature combiner
+      m.surf_channels.push_back({k, SRC_SURF, (int)i, tr});
+      m.surf_heads.push_back(k);
+      m.surf_out.push_back(k);
     }
-  };
+    for (const auto& k : m.surf_inputs)
+      if (contains(m.mod_heads, k)) m.surf_heads.push_back(k + "_mod");
+  }
+  for (size_t i = 0; i < m.static_vars.size(); ++i) m.surf_channels.push_back({m.static_vars[i], SRC_STATIC, (int)i, 0});
+  if (m.dynamic_vars)
+    for (int i = 0; i < 6; ++i) m.surf_channels.push_back({DYNAMIC_NAMES[i], SRC_DYN, i, 0});
 
-  float* xf = x_f;
-  void* xb = x_b;
-  for (int i = 0; i < n; ++i) {
-    run_blocks(m.enc_depths[i], xf, xb, i, nullptr, 0);
-    skips.push_back(xf);
-    if (i < n - 1) {
-      const Res r = m.stage_res[i];
-      REQUIRE(r.h > 1 && r.w > 1, "grid (%d, %d, %d) too small to merge", r.c, r.h, r.w);
-      const int dim = m.stage_dim(i);
-      const int H2 = (r.h + 1) / 2, W2 = (r.w + 1) / 2;
-      const int64_t M2 = (int64_t)B * r.c * H2 * W2;
-      float* nf = (float*)A.take((size_t)M2 * 2 * dim * 4);
-      void* nb = bf ? A.take((size_t)M2 * 2 * dim * 2) : nullptr;
-      const size_t mark = A.top;
-      void* mg = A.take((size_t)M2 * 4 * dim * es);
-      timed(m, stream, K_MERGE_LN, 0.0, [&] { return aurora_hip_merge_ln(xf, m.merges[i].ln_w, m.merges[i].ln_b, mg, B, r.c, r.h, r.w, dim, 1e-5f, bb, stream); });
-      if (bf) L.linear(mg, 4 * dim, m.merges[i].w, 4 * dim, nullptr, nb, 2 * dim, M2, 2 * dim, 4 * dim, bb, 0, nf, 2 * dim);
-      else L.linear(mg, 4 * dim, m.merges[i].w, 4 * dim, nullptr, nf, 2 * dim, M2, 2 * dim, 4 * dim, bb);
-      A.top = mark;
-      xf = nf;
-      xb = nb;
+  for (size_t i = 0; i < m.atmos_vars.size(); ++i) {
+    const std::string& k = m.atmos_vars[i];
+    const int tr = contains(m.pos_atmos, k) ? (m.variant == 1 ? 2 : 1) : 0;
+    m.atmos_channels.push_back({k, SRC_ATMOS, (int)i, tr});
+    m.atmos_heads.push_back(k);
+  }
+  for (const auto& k : m.atmos_vars)
+    if (contains(m.mod_heads, k)) m.atmos_heads.push_back(k + "_mod");
+  if (m.atmos_static_vars) {
+    // static (and dynamic) variables at every level; prefixed when the dynamic ones are there (encoder.py:248-269)
+    const std::string pre = m.dynamic_vars ? "static_" : "";
+    for (size_t i = 0; i < m.static_vars.size(); ++i) m.atmos_channels.push_back({pre + m.static_vars[i], SRC_STATIC, (int)i, 0});
+    if (m.dynamic_vars)
+      for (int i = 0; i < 6; ++i) m.atmos_channels.push_back({pre + DYNAMIC_NAMES[i], SRC_DYN, i, 0});
+  }
+  if (m.index_bug) {
+    // the slot of `static_z` is fed with `z`'s data (encoder.py:293-303, compat.py:156-159)
+    int iz = -1, isz = -1;
+    for (size_t i = 0; i < m.atmos_channels.size(); ++i) {
+      if (m.atmos_channels[i].name == "z") iz = (int)i;
+      if (m.atmos_channels[i].name == "static_z") isz = (int)i;
+    }
+    if (iz >= 0) {
+      REQUIRE(isz >= 0, "'static_z' is not in list");
+      Channel c = m.atmos_channels[iz];
+      c.name = "static_z";
+      m.atmos_channels[isz] = c;
     }
   }
-  for (int i = 0; i < n; ++i) {
-    const int idx = n - 1 - i;
-    const bool last_layer = i == n - 1;
-    run_blocks(m.dec_depths[i], xf, xb, idx, last_layer ? x_cat : nullptr, 2 * D);
-    if (last_layer && m.dec_depths[i] == 0 && !m.dry)
-      ok(aurora_hip_copy2d(xf, D, x_cat, 2 * D, (int64_t)B * L0, D, AURORA_F32, stream));
-    if (i < n - 1) {
-      const Res r = m.stage_res[idx];
-      const int dim = m.stage_dim(idx);
-      const void* a_in = bf ? xb : (const void*)xf;
-      const int crop_h = m.merge_pad[idx - 1][0], crop_w = m.merge_pad[idx - 1][1];
-      const int Ho = 2 * r.h - crop_h, Wo = 2 * r.w - crop_w;
-      const int64_t M1 = (int64_t)B * r.c * r.h * r.w, M2 = (int64_t)B * r.c * Ho * Wo;
-      float* nf = (float*)A.take((size_t)M2 * (dim / 2) * 4);
-      void* nb = bf ? A.take((size_t)M2 * (dim / 2) * 2) : nullptr;
-      const size_t mark = A.top;
-      void* y1 = A.take((size_t)M1 * 2 * dim * es);
-      L.linear(a_in, dim, m.splits[i].w1, dim, nullptr, y1, 2 * dim, M1, 2 * dim, dim, bb);
-      void* sp = A.take((size_t)M2 * (dim / 2) * es);
-      timed(m, stream, K_SPLIT_LN, 0.0, [&] { return aurora_hip_split_ln(y1, m.splits[i].ln_w, m.splits[i].ln_b, sp, B, r.c, r.h, r.w, dim / 2, crop_h, crop_w, 1e-5f, bb,
-                               stream); });
-      // additive skip after the intermediate decoder stages (swin3d.py:930-932)
-      const float* res_ = (i > 0 && i < n - 1) ? skips[idx - 1] : nullptr;
-      if (bf) L.linear(sp, dim / 2, m.splits[i].w2, dim / 2, nullptr, nb, dim / 2, M2, dim / 2, dim / 2, bb, 0, nf, dim / 2, res_, dim / 2);
-      else L.linear(sp, dim / 2, m.splits[i].w2, dim / 2, nullptr, nf, dim / 2, M2, dim / 2, dim / 2, bb, 0, nullptr, 0, res_, dim / 2);
-      A.top = mark;
-      xf = nf;
-      xb = nb;
-    }
-  }
-  timed(m, stream, K_COPY2D, 0.0, [&] { return aurora_hip_copy2d(skips[0], D, x_cat + D, 2 * D, (int64_t)B * L0, D, AURORA_F32, stream); });
+}
 
-  // ================= decoder (decoder.py:168-276) =================
-  const int D2 = 2 * D;
-  const int H = Hp * P, Wd = Wp * P;
-  {
-    const size_t mark = A.top;
-    // ---- surface heads on latent level 0 ----
-    const int n_s = n_surf * PP, ld_s = round_up(n_s, 4);
-    float* y_s = (float*)A.take((size_t)B * Lp * ld_s * 4);
-    for (int b = 0; b < B; ++b)
-      L.linear(x_cat + (size_t)b * Cl * Lp * D2, D2, m.head_surf_w.f(), D2, m.head_surf_b.f(), y_s + (size_t)b * Lp * ld_s, ld_s, Lp,
-               n_s, D2, AURORA_F32);
-    std::vector<aurora_unpatch_var> ud;
-    for (int v = 0; v < n_surf; ++v) {
-      aurora_unpatch_var d{};
-      d.dst = io.out_surf[v];
-      d.loc = st + m.surf_stat_off[v];
-      d.scale = st + m.surf_stat_off[v] + 1;
-      d.col0 = v * PP;
-      d.mod_col0 = d.angle_col0 = d.dens_col0 = -1;
-      ud.push_back(d);
+// Fused decoder heads of a group of variables: [groups][n * P * P][2D] weights, V fastest inside a patch is handled by
+// unpatchify's col0.  groups > 1: one head per pressure level (levelcond.py:36-69).
+void build_heads(Model& m, HeadGroup& hg, const char* kind, const std::vector<std::string>& names, bool per_level) {
+  const int PP = m.P * m.P, D2 = 2 * m.D;
+  hg.names = names;
+  hg.groups = per_level ? m.n_levels : 1;
+  if (names.empty()) return;
+  hg.w = DevBuf((size_t)hg.groups * names.size() * PP * D2 * 4);
+  hg.b = DevBuf((size_t)hg.groups * names.size() * PP * 4);
+  for (int g = 0; g < hg.groups; ++g)
+    for (size_t v = 0; v < names.size(); ++v) {
+      std::string p = std::string("decoder.") + kind + "_heads." + names[v];
+      if (per_level) p += ".layers." + level_to_str(m.levels[g]);
+      const Tensor& wt = m.T_(p + ".weight");
+      REQUIRE(wt.shape.size() == 2 && wt.shape[0] == PP && wt.shape[1] == D2, "bad head weight shape for %s", p.c_str());
+      hip_ok(hipMemcpy(hg.w.f() + ((size_t)g * names.size() + v) * PP * D2, wt.f(), (size_t)PP * D2 * 4, hipMemcpyDeviceToDevice), "copy");
+      hip_ok(hipMemcpy(hg.b.f() + ((size_t)g * names.size() + v) * PP, m.W(p + ".bias"), (size_t)PP * 4, hipMemcpyDeviceToDevice), "copy");
     }
-    for (size_t i = 0; i < ud.size(); i += 32)
-      timed(m, stream, K_UNPATCHIFY, 0.0, [&] {
-        return aurora_hip_unpatchify(y_s, ld_s, ud.data() + i, (int)std::min<size_t>(32, ud.size() - i), B, 1, Hp, Wp, P, stream);
-      });
-
-    // ---- level de-aggregation ----
-    const float* ctx = x_cat + (size_t)Lp * D2;
-    float* ctx_copy = nullptr;
-    if (B > 1) {   // latent levels 1.. of every batch element, made contiguous
-      ctx_copy = (float*)A.take((size_t)B * (Cl - 1) * Lp * D2 * 4);
-      for (int b = 0; b < B; ++b)
-        timed(m, stream, K_COPY2D, 0.0, [&] {
-          return aurora_hip_copy2d(x_cat + ((size_t)b * Cl * Lp + Lp) * D2, D2, ctx_copy + (size_t)b * (Cl - 1) * Lp * D2, D2,
-                                   (int64_t)(Cl - 1) * Lp, D2, AURORA_F32, stream);
-        });
-      ctx = ctx_copy;
-    }
-    size_t rs_mark = 0;
-    float* lat = resampler(m, L, m.dec_rs, ctx, (int64_t)B * (Cl - 1) * Lp, D2, m.dec_q.f(), m.dec_queries.f(), B, Lp,
-                           (int64_t)(Cl - 1) * Lp, Lp, C, Cl - 1, m.perceiver_heads, m.ln_eps, rs_mark);
-    const int n_a = n_atmos * PP, ld_a = round_up(n_a, 4);
-    float* y_a = (float*)A.take((size_t)B * Lp * C * ld_a * 4);
-    L.linear(lat, D2, m.head_atmos_w.f(), D2, m.head_atmos_b.f(), y_a, ld_a, (int64_t)B * Lp * C, n_a, D2, AURORA_F32);
-    std::vector<aurora_unpatch_var> ad;
-    for (int v = 0; v < n_atmos; ++v) {
-      aurora_unpatch_var d{};
-      d.dst = io.out_atmos[v];
-      d.loc = st + m.atmos_stat_off[v];
-      d.scale = st + m.atmos_stat_off[v] + C;
-      d.col0 = v * PP;
-      d.mod_col0 = d.angle_col0 = d.dens_col0 = -1;
-      ad.push_back(d);
-    }
-    for (size_t i = 0; i < ad.size(); i += 32)
-      timed(m, stream, K_UNPATCHIFY, 0.0, [&] {
-        return aurora_hip_unpatchify(y_a, ld_a, ad.data() + i, (int)std::min<size_t>(32, ad.size() - i), B, C, Hp, Wp, P, stream);
-      });
-    A.top = mark;
-  }
-  (void)H; (void)Wd;
-  return x_cat;
 }
 
 }  // namespace
+
+}  // namespace aurora
+
+using namespace aurora;
 
 // ====================================================================================================
 // C ABI
@@ -1105,11 +590,34 @@ extern "C" int aurora_hip_create(const aurora_hip_config* c, aurora_hip_model** 
     m->stabilise = c->stabilise_level_agg != 0; m->use_lora = c->use_lora != 0;
     m->lora_steps = c->lora_steps; m->lora_mode = c->lora_mode; m->autocast = c->autocast != 0;
     REQUIRE(m->lora_mode >= 0 && m->lora_mode <= 2, "create: lora_mode must be 0 (single), 1 (from_second) or 2 (all)");
-    for (int i = 0; i < c->n_surf; ++i) m->surf_vars.push_back(c->surf_vars[i]);
-    for (int i = 0; i < c->n_static; ++i) m->static_vars.push_back(c->static_vars[i]);
-    for (int i = 0; i < c->n_atmos; ++i) m->atmos_vars.push_back(c->atmos_vars[i]);
+    auto names = [](const char* const* p, int n, std::vector<std::string>& dst) {
+      for (int i = 0; i < n; ++i) dst.push_back(p[i]);
+    };
+    names(c->surf_vars, c->n_surf, m->surf_vars);
+    names(c->static_vars, c->n_static, m->static_vars);
+    names(c->atmos_vars, c->n_atmos, m->atmos_vars);
     REQUIRE(!m->surf_vars.empty() && !m->atmos_vars.empty(), "create: variable lists must not be empty");
+    // ---- variant keywords ----
+    m->variant = c->variant;
+    REQUIRE(m->variant >= 0 && m->variant <= 2, "create: variant must be 0 (base), 1 (air pollution) or 2 (ocean wave)");
+    for (int i = 0; i < c->n_level_condition; ++i) m->level_condition.push_back(c->level_condition[i]);
+    m->dynamic_vars = c->dynamic_vars != 0; m->atmos_static_vars = c->atmos_static_vars != 0;
+    m->clamp_first = c->clamp_at_first_step != 0; m->index_bug = c->simulate_indexing_bug != 0;
+    names(c->separate_perceiver, c->n_separate_perceiver, m->sep_perceiver);
+    names(c->modulation_heads, c->n_modulation_heads, m->mod_heads);
+    names(c->positive_surf_vars, c->n_positive_surf, m->pos_surf);
+    names(c->positive_atmos_vars, c->n_positive_atmos, m->pos_atmos);
+    names(c->surf_inputs, c->n_surf_inputs, m->surf_inputs);
+    names(c->density_channel_surf_vars, c->n_density, m->density_vars);
+    names(c->angle_surf_vars, c->n_angle, m->angle_vars);
+    if (m->surf_inputs.empty()) m->surf_inputs = m->surf_vars;
+    REQUIRE(m->variant == 2 || m->surf_inputs == m->surf_vars, "create: surf_inputs are for the ocean-wave variant");
+    if (c->difference_history)
+      for (int i = 0; i < c->n_modulation_heads; ++i)
+        if (c->difference_history[i] >= 0) m->diff_index[m->mod_heads[i]] = c->difference_history[i];
+    REQUIRE(m->static_vars.size() <= 60 && m->surf_inputs.size() <= 60 && m->atmos_vars.size() <= 60, "create: too many variables");
     build_blocks(*m);
+    build_channels(*m);
     m->ctx_max = DevBuf(16);
     *out = m.release();
   })
@@ -1230,7 +738,7 @@ extern "C" int aurora_hip_finalize(aurora_hip_model* mp, void* stream) {
   GUARDED({
     REQUIRE(mp != nullptr, "finalize: null model");
     Model& m = *mp;
-    m.keep.clear(); m.attn_sets.clear(); m.embed_w.clear(); m.embed_ws.clear(); m.embed_l1.clear(); m.merges.clear(); m.splits.clear();
+    m.keep.clear(); m.attn_sets.clear(); m.embed_packs.clear(); m.merges.clear(); m.splits.clear();
     Launcher L{m, stream};
     const int D = m.D;
     {   // ---- surface MLP: constants of its guarded two-term chain ----
@@ -1321,21 +829,29 @@ extern "C" int aurora_hip_finalize(aurora_hip_model* mp, void* stream) {
     if (l0.ln_q_w)
       L.layernorm(m.enc_q0.p, l0.inner, l0.ln_q_w, l0.ln_q_b, nullptr, 0, 0, m.enc_q0.f(), l0.inner, nullptr, 0, n_lat, l0.inner,
                   1e-5f, AURORA_F32);
-    // ---- decoder heads, fused over the variables (V fastest inside a patch is handled by unpatchify's col0) ----
-    auto fuse_heads = [&](const char* kind, const std::vector<std::string>& names, DevBuf& wd, DevBuf& bd) {
-      const int PP = m.P * m.P, D2 = 2 * D;
-      wd = DevBuf((size_t)names.size() * PP * D2 * 4);
-      bd = DevBuf((size_t)names.size() * PP * 4);
-      for (size_t v = 0; v < names.size(); ++v) {
-        const std::string p = std::string("decoder.") + kind + "_heads." + names[v];
-        const Tensor& wt = m.T_(p + ".weight");
-        REQUIRE(wt.shape.size() == 2 && wt.shape[0] == PP && wt.shape[1] == D2, "bad head weight shape for %s", p.c_str());
-        hip_ok(hipMemcpy(wd.f() + v * PP * D2, wt.f(), (size_t)PP * D2 * 4, hipMemcpyDeviceToDevice), "copy");
-        hip_ok(hipMemcpy(bd.f() + v * PP, m.W(p + ".bias"), (size_t)PP * 4, hipMemcpyDeviceToDevice), "copy");
-      }
-    };
-    fuse_heads("surf", m.surf_vars, m.head_surf_w, m.head_surf_b);
-    fuse_heads("atmos", m.atmos_vars, m.head_atmos_w, m.head_atmos_b);
+    // ---- second decoder Perceiver for the variables of `separate_perceiver` (decoder.py:232-248) ----
+    std::vector<std::string> sep = m.sep_perceiver;
+    if (!m.mod_heads.empty())
+      for (const auto& v : m.sep_perceiver) sep.push_back(v + "_mod");
+    m.has_alt = !sep.empty();
+    if (m.has_alt) m.dec_rs_alt = pack_resampler(m, "decoder.level_decoder_alternate", m.dec_depth, m.perceiver_heads);
+    // ---- decoder heads, fused over the variables of a group (level-conditioned atmospheric heads: per level set) ----
+    build_heads(m, m.head_surf, "surf", m.surf_heads, false);
+    if (m.level_condition.empty()) {
+      std::vector<std::string> main_names, alt_names;
+      for (const auto& n : m.atmos_heads) (contains(sep, n) ? alt_names : main_names).push_back(n);
+      build_heads(m, m.head_main, "atmos", main_names, false);
+      build_heads(m, m.head_alt, "atmos", alt_names, false);
+    }
+    // ---- air pollution: Linear(2, 1) feature combiners of the positive variables (aurora.py:733-742) ----
+    for (int kind = 0; kind < 2; ++kind)
+      for (Channel& ch : kind == 0 ? m.surf_channels : m.atmos_channels)
+        if (ch.transform == 2) {
+          const std::string p = std::string(kind == 0 ? "surf" : "atmos") + "_feature_combiner." + ch.name;
+          const std::vector<float> wv = to_host(m.T_(p + ".weight")), bv = to_host(m.T_(p + ".bias"));
+          REQUIRE(wv.size() == 2 && bv.size() == 1, "bad feature combiner shape for %s", p.c_str());
+          ch.tw0 = wv[0]; ch.tw1 = wv[1]; ch.tb = bv[0];
+        }
     hip_ok(hipStreamSynchronize(as_stream(stream)), "finalize sync");   // temporaries above die here
     m.finalized = true;
   })
@@ -1351,6 +867,57 @@ extern "C" int aurora_hip_pos_scale_encoding(const double* lat, const double* lo
   })
 }
 
+extern "C" int aurora_hip_set_band(aurora_hip_model* mp, const aurora_hip_band* band) {
+  GUARDED({
+    REQUIRE(mp != nullptr, "set_band: null model");
+    Model& m = *mp;
+    if (band == nullptr || band->world <= 1) {
+      m.band = aurora_hip_band{0, 1, nullptr, nullptr, nullptr};
+    } else {
+      REQUIRE(band->rank >= 0 && band->rank < band->world, "set_band: rank %d of %d", band->rank, band->world);
+      REQUIRE(band->post && band->wait, "set_band: the halo transport callbacks are required");
+      m.band = *band;
+    }
+    m.have_grid = false;   // the grid tables are per band: precompute again
+    m.plans.clear(); m.rows.clear();
+    m.stage_send[0] = m.stage_send[1] = m.stage_recv[0] = m.stage_recv[1] = nullptr;
+    m.staging_bytes = m.staging_need = 0;
+  })
+}
+
+extern "C" int aurora_hip_band_rows(const aurora_hip_model* m, int32_t* row0, int32_t* row1) {
+  GUARDED({
+    REQUIRE(m && row0 && row1 && m->have_grid, "band_rows: precompute the grid first");
+    const int h0 = m->sharded() ? m->rows[0][m->band.rank][0] : 0;
+    *row0 = h0 * m->P;
+    *row1 = (h0 + m->Hp) * m->P;
+  })
+}
+
+extern "C" int64_t aurora_hip_band_staging_bytes(const aurora_hip_model* m) { return m ? m->staging_need : 0; }
+
+extern "C" int aurora_hip_set_band_staging(aurora_hip_model* m, void* const send[2], void* const recv[2], int64_t staging_bytes) {
+  GUARDED({
+    REQUIRE(m && send && recv, "set_band_staging: null argument");
+    REQUIRE(staging_bytes >= m->staging_need, "set_band_staging: %lld bytes per buffer, %lld needed", (long long)staging_bytes,
+            (long long)m->staging_need);
+    for (int s = 0; s < 2; ++s) {
+      REQUIRE(m->staging_need == 0 || (send[s] && recv[s] && (uintptr_t)send[s] % 16 == 0 && (uintptr_t)recv[s] % 16 == 0),
+              "set_band_staging: four 16-byte aligned device buffers are required");
+      m->stage_send[s] = send[s];
+      m->stage_recv[s] = recv[s];
+    }
+    m->staging_bytes = staging_bytes;
+  })
+}
+
+extern "C" int aurora_hip_output_vars(const aurora_hip_model* m, const char** names, int capacity) {
+  if (!m) return 0;
+  if (names)
+    for (int i = 0; i < capacity && i < (int)m->surf_out.size(); ++i) names[i] = m->surf_out[i].c_str();
+  return (int)m->surf_out.size();
+}
+
 extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid* g, void* stream) {
   GUARDED({
     REQUIRE(mp && g, "precompute: null argument");
@@ -1361,28 +928,36 @@ extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid
     REQUIRE(g->n_lon % P == 0, "Width of the data must be a multiple of the patch size.");
     REQUIRE(g->n_lat % P == 0 || g->n_lat % P == 1, "There can at most be one latitude too many.");
     const int H = g->n_lat - g->n_lat % P, W = g->n_lon;
-    m.n_lat = H; m.n_lon = W; m.Hp = H / P; m.Wp = W / P;
-    const int64_t Lp = (int64_t)m.Hp * m.Wp;
-    // ---- stage resolutions (swin3d.py:868-882) ----
-    m.stage_res.clear(); m.merge_pad.clear(); m.tables.clear();
-    m.stage_res.push_back({m.Cl, m.Hp, m.Wp});
-    for (int s = 1; s < m.n_stages; ++s) {
-      const Res r = m.stage_res.back();
-      m.merge_pad.push_back({r.h % 2, r.w % 2});
-      m.stage_res.push_back({r.c, (r.h + r.h % 2) / 2, (r.w + r.w % 2) / 2});
-    }
+    m.full_Hp = H / P; m.Wp = W / P; m.n_lon = W;
+    // ---- stage resolutions of the whole grid (swin3d.py:868-882) ----
+    m.stage_res = stage_resolutions(Res{m.Cl, m.full_Hp, m.Wp}, m.n_stages);
+    m.merge_pad.clear(); m.tables.clear(); m.plans.clear(); m.embed_packs.clear();
+    for (int s = 0; s + 1 < m.n_stages; ++s) m.merge_pad.push_back({m.stage_res[s].h % 2, m.stage_res[s].w % 2});
     m.merge_pad.push_back({0, 0});
+    // ---- this rank's rows: everything (un-sharded) or a latitude band ----
+    int h0 = 0;
+    m.Hp = m.full_Hp;
+    m.rows.clear();
+    if (m.sharded()) {
+      if (!band_rows(m.stage_res, m.window, m.band.world, m.rows)) throw Fail{AURORA_E_ARG};
+      h0 = m.rows[0][m.band.rank][0];
+      m.Hp = m.rows[0][m.band.rank][1] - h0;
+    }
+    m.n_lat = m.Hp * P;
+    const int64_t Lp_full = (int64_t)m.full_Hp * m.Wp, Lp = (int64_t)m.Hp * m.Wp;
     // ---- position / scale encodings of the patch grid (posencoding.py:61-192) ----
-    std::vector<float> pos((size_t)Lp * D), scale((size_t)Lp * D);
+    std::vector<float> pos((size_t)Lp_full * D), scale((size_t)Lp_full * D);
     if (g->pos_encoding && g->scale_encoding) {
       memcpy(pos.data(), g->pos_encoding, pos.size() * 4);
       memcpy(scale.data(), g->scale_encoding, scale.size() * 4);
     } else {
       REQUIRE(g->lat && g->lon, "precompute: latitudes / longitudes (or the encodings themselves) are required");
-      pos_scale_tables(g->lat, g->lon, m.Hp, m.Wp, P, D, pos.data(), scale.data());
+      pos_scale_tables(g->lat, g->lon, m.full_Hp, m.Wp, P, D, pos.data(), scale.data());
     }
     {
-      DevBuf d_pos = to_device(pos), d_scale = to_device(scale), pe((size_t)Lp * D * 4);
+      DevBuf d_pos((size_t)Lp * D * 4), d_scale((size_t)Lp * D * 4), pe((size_t)Lp * D * 4);
+      upload(d_pos.p, pos.data() + (size_t)h0 * m.Wp * D, (size_t)Lp * D * 4);       // the band's patch rows
+      upload(d_scale.p, scale.data() + (size_t)h0 * m.Wp * D, (size_t)Lp * D * 4);
       m.pos_scale = DevBuf((size_t)Lp * D * 4);
       L.linear(d_pos.p, D, m.W("encoder.pos_embed.weight"), D, m.W("encoder.pos_embed.bias"), pe.p, D, Lp, D, D, AURORA_F32);
       L.linear(d_scale.p, D, m.W("encoder.scale_embed.weight"), D, m.W("encoder.scale_embed.bias"), m.pos_scale.p, D, Lp, D, D,
@@ -1391,70 +966,130 @@ extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid
     }
     // ---- pressure levels: per-level patch-embedding bias, decoder queries (encoder.py:318-330, decoder.py:176-200) ----
     const int C = g->n_levels;
-    REQUIRE(C >= 1 && g->levels, "precompute: pressure levels are required");
+    REQUIRE(C >= 1 && C <= 32 && g->levels, "precompute: 1..32 pressure levels are required");
     m.n_levels = C;
-    std::vector<double> lv(C);
-    for (int c = 0; c < C; ++c) lv[c] = g->levels_float32 ? (double)(float)g->levels[c] : g->levels[c];
+    m.levels.assign(C, 0.0);
+    for (int c = 0; c < C; ++c) m.levels[c] = g->levels_float32 ? (double)(float)g->levels[c] : g->levels[c];
     {
       std::vector<float> enc((size_t)C * D), dec((size_t)C * 2 * D);
-      fourier(LEVELS, lv.data(), C, D, enc.data());
-      fourier(LEVELS, lv.data(), C, 2 * D, dec.data());
+      fourier(LEVELS, m.levels.data(), C, D, enc.data());
+      fourier(LEVELS, m.levels.data(), C, 2 * D, dec.data());
       DevBuf d_enc = to_device(enc), d_dec = to_device(dec);
       m.enc_bias = DevBuf((size_t)C * D * 4);
-      L.linear(d_enc.p, D, m.W("encoder.atmos_levels_embed.weight"), D, m.W("encoder.atmos_levels_embed.bias"), m.enc_bias.p, D, C,
-               D, D, AURORA_F32, 0, nullptr, 0, m.W("encoder.atmos_token_embeds.bias"), 0);
+      if (m.level_condition.empty()) {
+        L.linear(d_enc.p, D, m.W("encoder.atmos_levels_embed.weight"), D, m.W("encoder.atmos_levels_embed.bias"), m.enc_bias.p, D, C,
+                 D, D, AURORA_F32, 0, nullptr, 0, m.W("encoder.atmos_token_embeds.bias"), 0);
+      } else {   // every level has its own patch embedding, bias included (levelcond.py:36-69)
+        DevBuf pb((size_t)C * D * 4);
+        for (int c = 0; c < C; ++c)
+          hip_ok(hipMemcpy(pb.f() + (size_t)c * D, m.W("encoder.atmos_token_embeds.layers." + level_to_str(m.levels[c]) + ".bias"),
+                           (size_t)D * 4, hipMemcpyDeviceToDevice), "copy");
+        L.linear(d_enc.p, D, m.W("encoder.atmos_levels_embed.weight"), D, m.W("encoder.atmos_levels_embed.bias"), m.enc_bias.p, D, C,
+                 D, D, AURORA_F32, 0, nullptr, 0, pb.f(), D);
+        hip_ok(hipStreamSynchronize(as_stream(stream)), "precompute sync");
+      }
       m.dec_queries = DevBuf((size_t)C * 2 * D * 4);
       L.linear(d_dec.p, 2 * D, m.W("decoder.atmos_levels_embed.weight"), 2 * D, m.W("decoder.atmos_levels_embed.bias"),
                m.dec_queries.p, 2 * D, C, 2 * D, 2 * D, AURORA_F32);
-      const auto& d0 = m.dec_rs.layers[0];
-      m.dec_q = DevBuf((size_t)C * d0.inner * 4);
-      L.linear(m.dec_queries.p, 2 * D, d0.to_q, 2 * D, nullptr, m.dec_q.p, d0.inner, C, d0.inner, 2 * D, AURORA_F32);
-      if (d0.ln_q_w)
-        L.layernorm(m.dec_q.p, d0.inner, d0.ln_q_w, d0.ln_q_b, nullptr, 0, 0, m.dec_q.f(), d0.inner, nullptr, 0, C, d0.inner, 1e-5f,
-                    AURORA_F32);
+      auto first_q = [&](const Resampler& rs, DevBuf& q) {
+        const auto& d0 = rs.layers[0];
+        q = DevBuf((size_t)C * d0.inner * 4);
+        L.linear(m.dec_queries.p, 2 * D, d0.to_q, 2 * D, nullptr, q.p, d0.inner, C, d0.inner, 2 * D, AURORA_F32);
+        if (d0.ln_q_w)
+          L.layernorm(q.p, d0.inner, d0.ln_q_w, d0.ln_q_b, nullptr, 0, 0, q.f(), d0.inner, nullptr, 0, C, d0.inner, 1e-5f, AURORA_F32);
+      };
+      first_q(m.dec_rs, m.dec_q);
+      if (m.has_alt) first_q(m.dec_rs_alt, m.dec_q_alt);
       hip_ok(hipStreamSynchronize(as_stream(stream)), "precompute sync");
       std::vector<float> eb((size_t)C * D);
       hip_ok(hipMemcpy(eb.data(), m.enc_bias.p, eb.size() * 4, hipMemcpyDeviceToHost), "download");
       m.enc_bias_max = 0.f;
       for (float v : eb) m.enc_bias_max = std::max(m.enc_bias_max, fabsf(v));
     }
+    if (!m.level_condition.empty()) {   // level-conditioned heads depend on the level set
+      std::vector<std::string> sep = m.sep_perceiver;
+      if (!m.mod_heads.empty())
+        for (const auto& v : m.sep_perceiver) sep.push_back(v + "_mod");
+      std::vector<std::string> main_names, alt_names;
+      for (const auto& n : m.atmos_heads) (contains(sep, n) ? alt_names : main_names).push_back(n);
+      build_heads(m, m.head_main, "atmos", main_names, true);
+      build_heads(m, m.head_alt, "atmos", alt_names, true);
+    }
     // ---- normalisation statistics: loc, scale, 1/scale (computed in fp64) per variable (and level) ----
-    const int ns = (int)m.surf_vars.size(), nst = (int)m.static_vars.size(), na = (int)m.atmos_vars.size();
+    const int ns = (int)m.surf_inputs.size(), nst = (int)m.static_vars.size(), na = (int)m.atmos_vars.size();
     REQUIRE(g->surf_loc && g->surf_scale && g->atmos_loc && g->atmos_scale && (nst == 0 || (g->static_loc && g->static_scale)),
             "precompute: normalisation statistics are required");
     std::vector<float> hs;
-    m.surf_stat_off.clear(); m.static_stat_off.clear(); m.atmos_stat_off.clear();
+    m.surf_stat_off.clear(); m.static_stat_off.clear(); m.atmos_stat_off.clear(); m.static_lvl_stat_off.clear(); m.static_loc.clear();
     auto push1 = [&](std::vector<size_t>& offs, double loc, double sc) {
       offs.push_back(hs.size());
       hs.push_back((float)loc); hs.push_back((float)sc); hs.push_back((float)(1.0 / sc)); hs.push_back(0.f);
     };
-    for (int v = 0; v < ns; ++v) push1(m.surf_stat_off, g->surf_loc[v], g->surf_scale[v]);
-    for (int v = 0; v < nst; ++v) push1(m.static_stat_off, g->static_loc[v], g->static_scale[v]);
-    for (int v = 0; v < na; ++v) {
-      m.atmos_stat_off.push_back(hs.size());
-      for (int c = 0; c < C; ++c) hs.push_back((float)g->atmos_loc[v * C + c]);
-      for (int c = 0; c < C; ++c) hs.push_back((float)g->atmos_scale[v * C + c]);
-      for (int c = 0; c < C; ++c) hs.push_back((float)(1.0 / g->atmos_scale[v * C + c]));
+    auto pushC = [&](std::vector<size_t>& offs, const double* loc, const double* sc, int stride) {   // C x loc | scale | 1/scale
+      offs.push_back(hs.size());
+      for (int c = 0; c < C; ++c) hs.push_back((float)loc[c * stride]);
+      for (int c = 0; c < C; ++c) hs.push_back((float)sc[c * stride]);
+      for (int c = 0; c < C; ++c) hs.push_back((float)(1.0 / sc[c * stride]));
       while (hs.size() % 4) hs.push_back(0.f);
+    };
+    for (int v = 0; v < ns; ++v) push1(m.surf_stat_off, g->surf_loc[v], g->surf_scale[v]);
+    for (int v = 0; v < nst; ++v) {
+      push1(m.static_stat_off, g->static_loc[v], g->static_scale[v]);
+      m.static_loc.push_back(g->static_loc[v]);
+    }
+    for (int v = 0; v < na; ++v) pushC(m.atmos_stat_off, g->atmos_loc + (size_t)v * C, g->atmos_scale + (size_t)v * C, 1);
+    // static variables fed at every level keep their surface statistics; dynamic planes are not normalised
+    for (int v = 0; v < nst; ++v) pushC(m.static_lvl_stat_off, g->static_loc + v, g->static_scale + v, 0);
+    {
+      const double zero = 0.0, one = 1.0;
+      std::vector<size_t> tmp;
+      pushC(tmp, &zero, &one, 0);
+      m.one_stat_off = tmp[0];
     }
     m.stats = to_device(hs);
+    // ---- a band's halo plans, and the staging each side of an exchange needs ----
+    m.staging_need = 0;
+    if (m.sharded())
+      for (int s = 0; s < m.n_stages; ++s)
+        for (int sh = 0; sh < 2; ++sh) {
+          const DevPlan& pl = plan_for(m, s, sh != 0);
+          const int64_t row_bytes = (int64_t)2 * m.stage_dim(s) * (int64_t)m.bbs();
+          for (int side = 0; side < 2; ++side)
+            m.staging_need = std::max(m.staging_need, std::max(pl.send_cnt[side], pl.recv_cnt[side]) * row_bytes);
+        }
     m.have_grid = true;
   })
 }
 
-extern "C" int aurora_hip_set_time(aurora_hip_model* mp, const double* time_hours, int B, void* stream) {
+namespace {
+// Civil date of a day count since 1970-01-01 (proleptic Gregorian; H. Hinnant's days_from_civil inverse).
+void civil_from_days(int64_t z, int& y, int& mth, int& d) {
+  z += 719468;
+  const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+  const unsigned doe = (unsigned)(z - era * 146097);
+  const unsigned yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  const unsigned doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  const unsigned mp = (5 * doy + 2) / 153;
+  d = (int)(doy - (153 * mp + 2) / 5 + 1);
+  mth = (int)(mp < 10 ? mp + 3 : mp - 9);
+  y = (int)(yoe + era * 400 + (mth <= 2));
+}
+}  // namespace
+
+extern "C" int aurora_hip_set_time_ex(aurora_hip_model* mp, const double* time_hours, const int32_t* calendar, int B, void* stream) {
   GUARDED({
     REQUIRE(mp && time_hours && B >= 1, "set_time: bad argument");
     Model& m = *mp;
     std::vector<double> t(B);
     // the reference converts the timestamps to a float32 tensor before expanding (encoder.py:359-362)
     for (int b = 0; b < B; ++b) t[b] = (double)(float)time_hours[b];
-    const size_t bytes = (size_t)B * m.D * 4;
     if (m.abs_B < B) {
       hip_ok(hipDeviceSynchronize(), "set_time");
-      m.abs_enc = DevBuf(bytes);
+      m.abs_enc = DevBuf((size_t)B * m.D * 4);
+      m.dyn_planes = DevBuf((size_t)6 * B * 4);
       m.abs_B = B;
     }
+    const size_t n_abs = (size_t)B * m.D, n_dyn = (size_t)6 * m.abs_B, bytes = (n_abs + n_dyn) * 4;
     auto& slot = m.pinned[m.pinned_next++ & 3];
     if (slot.done) hip_ok(hipEventSynchronize(slot.done), "set_time");   // the copy that used this slot four uploads ago
     else hip_ok(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming), "set_time");
@@ -1464,9 +1099,33 @@ extern "C" int aurora_hip_set_time(aurora_hip_model* mp, const double* time_hour
       slot.bytes = bytes;
     }
     fourier(ABS_TIME, t.data(), B, m.D, slot.host);
-    hip_ok(hipMemcpyAsync(m.abs_enc.p, slot.host, bytes, hipMemcpyHostToDevice, as_stream(stream)), "set_time");
+    // time of day / day of week / "day of year" planes of the dynamic variables (encoder.py:226-246: the last really is the
+    // day of the MONTH over 365.25), plane i of batch element b at [i][b]
+    float* dyn = slot.host + n_abs;
+    for (size_t i = 0; i < n_dyn; ++i) dyn[i] = 0.f;
+    for (int b = 0; b < B; ++b) {
+      int hour, weekday, day;
+      if (calendar) { hour = calendar[3 * b]; weekday = calendar[3 * b + 1]; day = calendar[3 * b + 2]; }
+      else {
+        const double hrs = time_hours[b];
+        const int64_t days = (int64_t)floor(hrs / 24.0);
+        hour = (int)floor(hrs - 24.0 * (double)days);
+        weekday = (int)(((days % 7) + 7 + 3) % 7);   // 1970-01-01 was a Thursday; Monday = 0
+        int y, mo;
+        civil_from_days(days, y, mo, day);
+      }
+      const double vals[6] = {cos(2 * PI * hour / 24), sin(2 * PI * hour / 24), cos(2 * PI * weekday / 7), sin(2 * PI * weekday / 7),
+                              cos(2 * PI * day / 365.25), sin(2 * PI * day / 365.25)};
+      for (int i = 0; i < 6; ++i) dyn[(size_t)i * m.abs_B + b] = (float)vals[i];
+    }
+    hip_ok(hipMemcpyAsync(m.abs_enc.p, slot.host, n_abs * 4, hipMemcpyHostToDevice, as_stream(stream)), "set_time");
+    hip_ok(hipMemcpyAsync(m.dyn_planes.p, dyn, n_dyn * 4, hipMemcpyHostToDevice, as_stream(stream)), "set_time");
     hip_ok(hipEventRecord(slot.done, as_stream(stream)), "set_time");
   })
+}
+
+extern "C" int aurora_hip_set_time(aurora_hip_model* mp, const double* time_hours, int B, void* stream) {
+  return aurora_hip_set_time_ex(mp, time_hours, nullptr, B, stream);
 }
 
 extern "C" int aurora_hip_step(aurora_hip_model* mp, const aurora_hip_step_io* io, void* stream) {
@@ -1478,7 +1137,12 @@ extern "C" int aurora_hip_step(aurora_hip_model* mp, const aurora_hip_step_io* i
     REQUIRE(io->T <= m.max_history, "%d > %d.", io->T, m.max_history);
     REQUIRE(m.abs_B >= io->B, "step: call aurora_hip_set_time for this batch first");
     REQUIRE(io->surf && io->atmos && io->out_surf && io->out_atmos && (m.static_vars.empty() || io->stat), "step: null field list");
-    StepIO s{io, io->B, io->T, m.n_lat, m.n_lon};
+    if (m.sharded()) {
+      REQUIRE(io->B == 1, "latitude-band sharding runs one forecast (batch size 1) across the ranks");
+      REQUIRE(m.staging_need == 0 || m.staging_bytes >= m.staging_need, "step: hand over the band's staging buffers first "
+              "(aurora_hip_set_band_staging, %lld bytes each)", (long long)m.staging_need);
+    }
+    StepIO s{io, io->B, io->T};
     // LoRA sets are merged outside the dry run (they allocate and launch)
     attn_weights(m, lora_key(m, io->rollout_step), stream);
     m.dry = true;
@@ -1500,6 +1164,12 @@ extern "C" int aurora_hip_step(aurora_hip_model* mp, const aurora_hip_step_io* i
     }
     run_step(m, s, stream);
   })
+}
+
+namespace {
+const char* const KIND_NAMES[K_COUNT] = {"linear_bf16", "linear_f32", "window_attention_bf16", "layernorm", "merge_ln",
+                                         "split_ln", "patchify", "perceiver_attention", "assemble_tokens", "unpatchify",
+                                         "copy2d", "absmax", "linear_layernorm_bf16", "gather_rows"};
 }
 
 extern "C" int aurora_hip_profile_begin(aurora_hip_model* m, uint32_t kind_mask) {
@@ -1529,6 +1199,15 @@ extern "C" int aurora_hip_profile_end(aurora_hip_model* m, aurora_hip_profile_en
     m->timed.clear();
     *n_out = K_COUNT;
   })
+}
+
+extern "C" int aurora_hip_abi_sizes(int32_t* out, int capacity) {
+  const int32_t sizes[] = {(int32_t)sizeof(aurora_hip_config), (int32_t)sizeof(aurora_hip_grid), (int32_t)sizeof(aurora_hip_step_io),
+                           (int32_t)sizeof(aurora_hip_band), (int32_t)sizeof(aurora_hip_halo_msg), (int32_t)sizeof(aurora_hip_plan_info),
+                           (int32_t)sizeof(aurora_patch_var), (int32_t)sizeof(aurora_unpatch_var), (int32_t)sizeof(aurora_hip_profile_entry)};
+  const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
+  for (int i = 0; i < n && i < capacity; ++i) out[i] = sizes[i];
+  return n;
 }
 
 extern "C" int64_t aurora_hip_workspace_bytes(const aurora_hip_model* m) { return m ? (int64_t)m->arena.cap : 0; }

@@ -498,7 +498,12 @@ def convert(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
 
 
 # ---- model handle (one forecast step behind the C ABI) ------------------------------------------------------
-class HipConfig(ctypes.Structure):
+_PD = ctypes.POINTER(ctypes.c_double)
+_PF = ctypes.POINTER(ctypes.c_float)
+_PS = ctypes.POINTER(ctypes.c_char_p)
+
+
+class HipConfig(ctypes.Structure):   # aurora_hip_config, field for field
     _fields_ = [("embed_dim", c_int32), ("patch_size", c_int32), ("latent_levels", c_int32), ("num_heads", c_int32),
                 ("n_stages", c_int32), ("encoder_depths", c_int32 * 4), ("encoder_heads", c_int32 * 4),
                 ("decoder_depths", c_int32 * 4), ("decoder_heads", c_int32 * 4), ("window", c_int32 * 3),
@@ -506,12 +511,32 @@ class HipConfig(ctypes.Structure):
                 ("max_history", c_int32), ("timestep_hours", ctypes.c_double), ("stabilise_level_agg", c_int32),
                 ("use_lora", c_int32), ("lora_steps", c_int32), ("lora_mode", c_int32), ("autocast", c_int32),
                 ("n_surf", c_int32), ("n_static", c_int32), ("n_atmos", c_int32),
-                ("surf_vars", ctypes.POINTER(ctypes.c_char_p)), ("static_vars", ctypes.POINTER(ctypes.c_char_p)),
-                ("atmos_vars", ctypes.POINTER(ctypes.c_char_p))]
+                ("surf_vars", _PS), ("static_vars", _PS), ("atmos_vars", _PS),
+                # variant keywords
+                ("variant", c_int32), ("n_level_condition", c_int32), ("level_condition", _PD),
+                ("dynamic_vars", c_int32), ("atmos_static_vars", c_int32), ("clamp_at_first_step", c_int32),
+                ("simulate_indexing_bug", c_int32),
+                ("n_separate_perceiver", c_int32), ("separate_perceiver", _PS),
+                ("n_modulation_heads", c_int32), ("modulation_heads", _PS),
+                ("difference_history", ctypes.POINTER(c_int32)),
+                ("n_positive_surf", c_int32), ("positive_surf_vars", _PS),
+                ("n_positive_atmos", c_int32), ("positive_atmos_vars", _PS),
+                ("n_surf_inputs", c_int32), ("surf_inputs", _PS),
+                ("n_density", c_int32), ("density_channel_surf_vars", _PS),
+                ("n_angle", c_int32), ("angle_surf_vars", _PS)]
 
 
-_PD = ctypes.POINTER(ctypes.c_double)
-_PF = ctypes.POINTER(ctypes.c_float)
+class HipHaloMsg(ctypes.Structure):   # aurora_hip_halo_msg
+    _fields_ = [("peer", c_int32), ("side", c_int32), ("data", c_void_p), ("bytes", c_int64)]
+
+
+HALO_POST_FN = ctypes.CFUNCTYPE(c_int, c_void_p, ctypes.POINTER(HipHaloMsg), c_int32, ctypes.POINTER(HipHaloMsg), c_int32,
+                                c_void_p)
+HALO_WAIT_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p)
+
+
+class HipBand(ctypes.Structure):      # aurora_hip_band
+    _fields_ = [("rank", c_int32), ("world", c_int32), ("post", HALO_POST_FN), ("wait", HALO_WAIT_FN), ("user", c_void_p)]
 
 
 class HipGrid(ctypes.Structure):
@@ -540,7 +565,8 @@ class HipPlanInfo(ctypes.Structure):
 
 
 PROFILE_KINDS = ("linear_bf16", "linear_f32", "window_attention_bf16", "layernorm", "merge_ln", "split_ln", "patchify",
-                 "perceiver_attention", "assemble_tokens", "unpatchify", "copy2d", "absmax", "linear_layernorm_bf16")
+                 "perceiver_attention", "assemble_tokens", "unpatchify", "copy2d", "absmax", "linear_layernorm_bf16",
+                 "gather_rows")
 
 _SIGNATURES.update({
     "aurora_hip_profile_begin": (c_int, [c_void_p, ctypes.c_uint32]),
@@ -555,6 +581,13 @@ _SIGNATURES.update({
     "aurora_hip_set_time": (c_int, [c_void_p, _PD, c_int, c_void_p]),
     "aurora_hip_step": (c_int, [c_void_p, ctypes.POINTER(HipStepIO), c_void_p]),
     "aurora_hip_workspace_bytes": (c_int64, [c_void_p]),
+    "aurora_hip_abi_sizes": (c_int, [ctypes.POINTER(c_int32), c_int]),
+    "aurora_hip_output_vars": (c_int, [c_void_p, _PS, c_int]),
+    "aurora_hip_set_time_ex": (c_int, [c_void_p, _PD, ctypes.POINTER(c_int32), c_int, c_void_p]),
+    "aurora_hip_set_band": (c_int, [c_void_p, ctypes.POINTER(HipBand)]),
+    "aurora_hip_band_rows": (c_int, [c_void_p, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]),
+    "aurora_hip_band_staging_bytes": (c_int64, [c_void_p]),
+    "aurora_hip_set_band_staging": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int64]),
     "aurora_hip_pos_scale_encoding": (c_int, [_PD, _PD, c_int, c_int, c_int, c_int, _PF, _PF]),
     "aurora_hip_band_partition": (c_int, [c_int, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32), c_int, c_int, c_int,
                                           ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]),

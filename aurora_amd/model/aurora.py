@@ -264,12 +264,9 @@ class Aurora(nn.Module):
 
     def save_packed(self, path: str) -> None:
         """Write the weights as a packed `AURORAHIP1` file for the C-ABI handle (`aurora_hip_load_packed`): no pickle,
-        the big backbone matrices in bf16 when `autocast` is on.  Not in the reference; ERA5 model family, on a HIP
+        the big backbone matrices in bf16 when `autocast` is on.  Not in the reference; the model must be on a HIP
         device."""
-        eng = self.engine()
-        if eng.native is None:
-            raise NotImplementedError("packed weight files are written by the C-ABI handle (ERA5 model family, one device)")
-        eng.native.save_packed(path)
+        self.engine().native.save_packed(path)
 
     def _adapt_checkpoint(self, d: dict[str, torch.Tensor]) -> dict[str, torch.Tensor]:
         return compat.adapt_pretrained(self.patch_size, d)

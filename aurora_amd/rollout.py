@@ -139,7 +139,8 @@ def _rollout_graphed(model, batch: Batch, steps: int) -> Generator[Batch, None, 
     stepper = None
     state = batch
     for _ in range(steps):
-        if stepper is None or engine.step_signature(stepper.state.metadata.rollout_step) != stepper.signature:
+        if (stepper is None or engine.step_signature(stepper.state.metadata.rollout_step) != stepper.signature
+                or stepper._handle_addresses() != stepper._addresses):   # (the handle re-allocated what the graph points at)
             if stepper is not None:
                 state = stepper.state   # continue from the captured state with a new weight set
             stepper = engine.capture(state)

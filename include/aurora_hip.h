@@ -416,6 +416,11 @@ int aurora_hip_pos_scale_encoding(const double* lat, const double* lon, int n_la
 int aurora_hip_set_time(aurora_hip_model* model, const double* time_hours, int B, void* stream);
 int aurora_hip_step(aurora_hip_model* model, const aurora_hip_step_io* io, void* stream);
 int64_t aurora_hip_workspace_bytes(const aurora_hip_model* model);
+/* sizeof() of the structs of this header as the library was compiled, in the order aurora_hip_config, aurora_hip_grid,
+ * aurora_hip_step_io, aurora_hip_band, aurora_hip_halo_msg, aurora_hip_plan_info, aurora_patch_var, aurora_unpatch_var,
+ * aurora_hip_profile_entry: a binding in another language checks its own struct declarations against them.  Returns the
+ * number of entries. */
+int aurora_hip_abi_sizes(int32_t* out, int capacity);
 /* Names of the surface variables a step predicts, in the order of aurora_hip_step_io.out_surf (ocean wave: the non-angle
  * variables, then the directions, aurora.py:914-932; otherwise the surface inputs).  Returns the count; `names` may be NULL. */
 int aurora_hip_output_vars(const aurora_hip_model* model, const char** names, int capacity);

@@ -41,6 +41,13 @@ def test_ctypes_structs_match_header_layout():
         "prev_sc", "prev_sh", "inv_scale", "clamp_max1_levels", "angle_col0", "dens_col0", "mask", "mask_sh",
         "mask_thresh"]
     assert ctypes.sizeof(shim.UnpatchVar) == 120
+    # ... and byte for byte with what the compiler made of every struct of the header
+    sizes = (ctypes.c_int32 * 16)()
+    n = shim.load().aurora_hip_abi_sizes(sizes, 16)
+    mine = [shim.HipConfig, shim.HipGrid, shim.HipStepIO, shim.HipBand, shim.HipHaloMsg, shim.HipPlanInfo, shim.PatchVar,
+            shim.UnpatchVar, shim.HipProfileEntry]
+    assert n == len(mine)
+    assert [ctypes.sizeof(t) for t in mine] == list(sizes[:n])
 
 
 def test_argument_errors_surface_without_a_gpu(built):

@@ -5,7 +5,8 @@ caller's job exactly as in aurora/rollout.py:39-49).  The predictions must match
 tolerance as the Python-facing API (tests/test_gpu_model.py): mean-rel <= 1e-4 per variable.
 
 The handle computes the Fourier position / scale tables itself here (lat / lon passed, no tables): the C++ restatement of
-posencoding.py:61-192 is what is being checked.
+posencoding.py:61-192 is what is being checked.  The air-pollution and ocean-wave variants go through the same seven
+functions (variant keywords in aurora_hip_config).
 """
 import ctypes
 
@@ -31,7 +32,7 @@ def _carr(ctype, values):
 class Handle:
     """The binding a maintainer of another host language would write, in ctypes."""
 
-    def __init__(self, cfg, autocast, state_dict=None, packed=None):
+    def __init__(self, cfg, autocast, state_dict=None, packed=None, variant=None):
         self.L = lib.load()
         self.cfg = cfg
         c = lib.HipConfig()
@@ -46,9 +47,33 @@ class Handle:
         c.max_history, c.timestep_hours = cfg.max_history_size, cfg.timestep.total_seconds() / 3600
         c.stabilise_level_agg, c.use_lora, c.lora_steps = int(cfg.stabilise_level_agg), int(cfg.use_lora), cfg.lora_steps
         c.lora_mode, c.autocast = _MODES[cfg.lora_mode], int(autocast)
-        self._names = [_carr(ctypes.c_char_p, [n.encode() for n in v]) for v in (cfg.surf_vars, cfg.static_vars, cfg.atmos_vars)]
+        strs = lambda v: _carr(ctypes.c_char_p, [n.encode() for n in v])  # noqa: E731
+        self._names = [strs(v) for v in (cfg.surf_vars, cfg.static_vars, cfg.atmos_vars)]
         c.n_surf, c.n_static, c.n_atmos = len(cfg.surf_vars), len(cfg.static_vars), len(cfg.atmos_vars)
         c.surf_vars, c.static_vars, c.atmos_vars = self._names
+        # variant keywords (aurora.py:86-95); `variant` = (code, extra) as a non-Python host would hard-wire them
+        self.surf_inputs = tuple(cfg.surf_vars)
+        if variant is not None:
+            code, extra = variant
+            c.variant = code
+            lc = tuple(cfg.level_condition or ())
+            diff = extra.get("difference_history", {})
+            self._vkeep = [_carr(ctypes.c_double, [float(x) for x in lc]), strs(cfg.separate_perceiver), strs(cfg.modulation_heads),
+                           _carr(ctypes.c_int32, [diff.get(v, -1) for v in cfg.modulation_heads]), strs(cfg.positive_surf_vars),
+                           strs(cfg.positive_atmos_vars), strs(extra.get("surf_inputs", ())), strs(extra.get("density", ())),
+                           strs(extra.get("angle", ()))]
+            c.n_level_condition, c.level_condition = len(lc), self._vkeep[0]
+            c.dynamic_vars, c.atmos_static_vars = int(cfg.dynamic_vars), int(cfg.atmos_static_vars)
+            c.clamp_at_first_step, c.simulate_indexing_bug = int(cfg.clamp_at_first_step), int(cfg.simulate_indexing_bug)
+            c.n_separate_perceiver, c.separate_perceiver = len(cfg.separate_perceiver), self._vkeep[1]
+            c.n_modulation_heads, c.modulation_heads, c.difference_history = len(cfg.modulation_heads), self._vkeep[2], self._vkeep[3]
+            c.n_positive_surf, c.positive_surf_vars = len(cfg.positive_surf_vars), self._vkeep[4]
+            c.n_positive_atmos, c.positive_atmos_vars = len(cfg.positive_atmos_vars), self._vkeep[5]
+            if extra.get("surf_inputs"):
+                self.surf_inputs = tuple(extra["surf_inputs"])
+                c.n_surf_inputs, c.surf_inputs = len(self.surf_inputs), self._vkeep[6]
+                c.n_density, c.density_channel_surf_vars = len(extra["density"]), self._vkeep[7]
+                c.n_angle, c.angle_surf_vars = len(extra["angle"]), self._vkeep[8]
         self.h = ctypes.c_void_p()
         self.check(self.L.aurora_hip_create(ctypes.byref(c), ctypes.byref(self.h)))
         if packed is not None:                       # a packed weight file instead of a state_dict
@@ -58,6 +83,10 @@ class Handle:
             shape = _carr(ctypes.c_int64, list(w.shape))
             self.check(self.L.aurora_hip_pack_weights(self.h, name.encode(), w.ctypes.data_as(ctypes.c_void_p), shape, w.ndim, 0, 0))
         self.check(self.L.aurora_hip_finalize(self.h, None))
+        n_out = self.L.aurora_hip_output_vars(self.h, None, 0)
+        names = (ctypes.c_char_p * n_out)()
+        self.L.aurora_hip_output_vars(self.h, names, n_out)
+        self.surf_outputs = tuple(x.decode() for x in names)
 
     def check(self, code):
         assert code == 0, self.L.aurora_hip_last_error().decode()
@@ -66,7 +95,7 @@ class Handle:
         cfg, g = self.cfg, lib.HipGrid()
         g.n_lat, g.n_lon, g.n_levels = len(lat), len(lon), len(levels)
         dbl = lambda v: _carr(ctypes.c_double, [float(x) for x in v])  # noqa: E731
-        sa = [normalisation.surf_affine(n) for n in cfg.surf_vars]
+        sa = [normalisation.surf_affine(n) for n in self.surf_inputs]
         ta = [normalisation.surf_affine(n) for n in cfg.static_vars]
         aa = [normalisation.atmos_affine(n, levels) for n in cfg.atmos_vars]
         keep = [dbl(lat), dbl(lon), dbl(levels), dbl([a[0] for a in sa]), dbl([a[1] for a in sa]), dbl([a[0] for a in ta]),
@@ -81,8 +110,9 @@ class Handle:
         B, T, H, W = surf[0].shape
         Hc = H - H % cfg.patch_size
         hours = _carr(ctypes.c_double, [t.timestamp() / 3600 for t in times])
-        self.check(self.L.aurora_hip_set_time(self.h, hours, B, None))
-        out_s = [torch.empty(B, Hc, W, device=DEV) for _ in surf]
+        cal = _carr(ctypes.c_int32, [x for t in times for x in (t.hour, t.weekday(), t.day)])
+        self.check(self.L.aurora_hip_set_time_ex(self.h, hours, cal, B, None))
+        out_s = [torch.empty(B, Hc, W, device=DEV) for _ in self.surf_outputs]
         out_a = [torch.empty(B, len(levels), Hc, W, device=DEV) for _ in atmos]
         io = lib.HipStepIO()
         io.B, io.T, io.rollout_step = B, T, rollout_step
@@ -135,32 +165,6 @@ def test_c_abi_rollout_matches_reference_golden(name):
     h.close()
 
 
-def test_c_abi_step_equals_python_sequenced_step(monkeypatch):
-    """The handle and the Python-sequenced engine launch the same kernels in the same order: bit-identical results
-    (fp32 and bf16), when both take their position / scale tables from the same source."""
-    from aurora_amd import Batch, Metadata
-
-    case = CASES["base_pad"]
-    for autocast in (False, True):
-        outs = []
-        for native in ("1", "0"):
-            monkeypatch.setenv("AURORA_NATIVE_STEP", native)
-            model = aurora_amd.Aurora(**case["kwargs"], autocast=autocast)
-            model.load_state_dict(helpers.case_state_dict(model, torch.float32))
-            model = model.to(DEV).eval()
-            surf, static, atmos, lat, lon, times = helpers.case_inputs(case, model.config)
-            g = lambda d: {k: v.float() for k, v in d.items()}  # noqa: E731
-            batch = Batch(g(surf), g(static), g(atmos), Metadata(lat.float(), lon.float(), times, tuple(case["levels"])))
-            with torch.inference_mode():
-                pred = model.forward(batch)
-            assert (model.engine().native is not None) == (native == "1")
-            outs.append(pred)
-        for k in outs[0].surf_vars:
-            assert torch.equal(outs[0].surf_vars[k], outs[1].surf_vars[k]), (autocast, k)
-        for k in outs[0].atmos_vars:
-            assert torch.equal(outs[0].atmos_vars[k], outs[1].atmos_vars[k]), (autocast, k)
-
-
 @pytest.mark.parametrize("name", ["base_pad", "lora_all"])
 def test_packed_weight_file_round_trip(name, tmp_path):
     """aurora_hip_save_packed -> aurora_hip_load_packed into a fresh handle: bit-identical bf16-backbone predictions,
@@ -193,6 +197,52 @@ def test_packed_weight_file_round_trip(name, tmp_path):
     assert raised
     a.close()
     b.close()
+
+
+def _variant_of(name, meta):
+    if name == "air_pollution":
+        return 1, {"difference_history": dict(type(meta)._predict_difference_history_dim_lookup)}
+    if name == "wave":
+        from aurora_amd.engine import native
+
+        return 2, {"surf_inputs": native.wave_sources(meta), "density": meta.density_channel_surf_vars,
+                   "angle": meta.angle_surf_vars}
+    return None
+
+
+@pytest.mark.parametrize("name", ["air_pollution", "wave"])
+def test_c_abi_variants_match_reference_golden(name):
+    """AuroraAirPollution (level-conditioned embeddings / heads, dynamic + static inputs, feature combiners, difference
+    prediction, second decoder Perceiver) and AuroraWave (density / sin / cos channels and their inverse) through the raw C
+    ABI: first roll-out step of the reference goldens.  (The wave variant's raw-batch preparation -- wind components, NaN
+    marking of absent systems, aurora.py:854-890 -- is host-side input preparation: `aurora_amd.model.wave`.)"""
+    from aurora_amd import Batch, Metadata
+    from aurora_amd.model import wave
+
+    case, meta = helpers.case_model_meta(name)
+    cfg = meta.config
+    sd = {k: v.numpy() for k, v in helpers.case_state_dict(meta, torch.float32).items()}
+    surf, static, atmos, lat, lon, times = helpers.case_inputs(case, cfg)
+    if name == "wave":
+        surf = wave.transform_batch(Batch(surf, static, atmos, Metadata(lat, lon, times, tuple(case["levels"])))).surf_vars
+    gold = helpers.load_golden(name)
+    levels = tuple(case["levels"])
+    h = Handle(cfg, autocast=False, state_dict=sd, variant=_variant_of(name, meta))
+    h.precompute(lat.tolist(), lon.tolist(), levels)
+    f = lambda d, names: [d[n].float().to(DEV).contiguous() for n in names]  # noqa: E731
+    out_s, out_a = h.step(f(surf, h.surf_inputs), f(static, cfg.static_vars), f(atmos, cfg.atmos_vars), times, 0, levels)
+    worst = 0.0
+    for kind, names, outs in (("surf", h.surf_outputs, out_s), ("atmos", cfg.atmos_vars, out_a)):
+        for n, o in zip(names, outs):
+            ref = torch.from_numpy(gold[f"s0.{kind}.{n}"])
+            got, ref, flipped = helpers.nan_agreement(o.cpu().reshape(ref.shape), ref)
+            assert flipped <= 2e-3, (n, flipped)
+            e = helpers.mean_rel_err(got, ref)
+            worst = max(worst, e)
+            assert e <= 1e-4 and helpers.rel_err(got, ref) <= 1e-3, (kind, n, e)
+    assert len(h.surf_outputs) + len(cfg.atmos_vars) == sum(k.startswith("s0.") for k in gold)
+    print(name, "C-ABI step worst mean-rel", worst)
+    h.close()
 
 
 def test_c_abi_argument_errors():

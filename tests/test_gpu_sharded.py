@@ -1,9 +1,10 @@
-"""Latitude-band sharding on ONE GPU: R engines of the same model run as virtual ranks in one process;
-their halo exchanges are carried out by copying exactly the tensors the plans name (the RCCL
-point-to-point path moves the same tensors between processes).  The stitched bands must equal the
-un-sharded engine."""
+"""Latitude-band sharding on ONE GPU: R handles of the same model run as virtual ranks in one process, one thread
+each; their halo exchanges are carried out by copying exactly the staging buffers the handle's `post` callback names
+(the RCCL point-to-point path moves the same bytes between processes).  The stitched bands must equal the un-sharded
+engine."""
 import dataclasses
-from collections import defaultdict, deque
+import queue
+import threading
 
 import pytest
 import torch
@@ -11,65 +12,102 @@ import torch
 import aurora_amd
 from aurora_amd import Batch, Metadata
 from aurora_amd.batch import BandBatch
-from aurora_amd.engine.engine import Complete, Engine, Shard
+from aurora_amd.engine import native
+from aurora_amd.engine.engine import Engine, Shard
 from tests import helpers
 from tests.golden_cases import CASES
 
 pytestmark = pytest.mark.gpu
 
 
+class VirtualTransport(native._Transport):
+    """The handle's halo callbacks for ranks that live in one process: a message is a device-to-device copy from the
+    sender's staging buffer into the receiver's.  All ranks launch on the same (default) stream, so "the copy is enqueued
+    after the sender's gather kernel" is all the ordering needed: the sender posts AFTER launching its gather, the
+    receiver copies in `wait`, and the sender's `wait` holds until its messages have been copied out (the next
+    exchange's gather overwrites the staging buffer)."""
+
+    TIMEOUT = 120.0
+
+    def __init__(self, rank, hub) -> None:
+        super().__init__(None, "cuda")
+        self.rank, self.hub = rank, hub
+        self.sent, self.expect = [], []
+
+    def _post(self, user, sends, n_sends, recvs, n_recvs, stream) -> int:
+        try:
+            for i in range(n_sends):
+                m = sends[i]
+                assert abs(m.peer - self.rank) == 1 and m.side == (0 if m.peer < self.rank else 1)
+                consumed = threading.Event()
+                self.hub.box(self.rank, m.peer).put((self.send[m.side][:m.bytes], consumed))
+                self.sent.append(consumed)
+            self.expect = [(recvs[i].peer, recvs[i].side, recvs[i].bytes) for i in range(n_recvs)]
+            self.hub.exchanges += 1
+            return 0
+        except BaseException as e:  # noqa: BLE001
+            self.error = e
+            return -1
+
+    def _wait(self, user, stream) -> int:
+        try:
+            for peer, side, n_bytes in self.expect:
+                src, consumed = self.hub.box(peer, self.rank).get(timeout=self.TIMEOUT)
+                assert src.numel() == n_bytes, (src.numel(), n_bytes)
+                self.recv[side][:n_bytes].copy_(src)
+                consumed.set()
+            for consumed in self.sent:
+                assert consumed.wait(self.TIMEOUT), "a halo message was never received"
+            self.sent, self.expect = [], []
+            return 0
+        except BaseException as e:  # noqa: BLE001
+            self.error = e
+            return -1
+
+
+class Hub:
+    def __init__(self) -> None:
+        self.boxes, self.lock, self.exchanges = {}, threading.Lock(), 0
+
+    def box(self, src, dst):
+        with self.lock:
+            return self.boxes.setdefault((src, dst), queue.Queue())
+
+
 def make_engines(model, world):
+    hub = Hub()
     engines = []
     for r in range(world):
         model._shard = Shard(r, world, None, gather_output=False)
-        engines.append(Engine(model))
+        engines.append(Engine(model, transport=VirtualTransport(r, hub)))
     model._shard = None
     return engines
 
 
 def run_virtual_ranks(model, batch, world, engines=None):
-    """Advance `world` sharded step generators until all finish; returns the per-rank BandBatches."""
+    """One sharded step on `world` virtual ranks (threads); returns the per-rank BandBatches and the number of exchanges
+    posted.  `batch`: the full batch, or a list with every rank's BandBatch."""
     engines = engines or make_engines(model, world)
-    gens = [e.step_gen(batch if not isinstance(batch, list) else batch[r]) for r, e in enumerate(engines)]
-    mailbox = defaultdict(deque)           # (src, dst) -> tensors in posting order
-    waiting, done = {}, {}
-    n_exchanges = 0
+    hub = engines[0].native.transport.hub
+    before = hub.exchanges
+    out, errors = [None] * world, []
 
-    def advance(r, first=False):
+    def run(r):
         try:
-            req = next(gens[r]) if first else gens[r].send(None)
-            while isinstance(req, Complete):   # (the harness completes every exchange before resuming a rank)
-                req = gens[r].send(None)
-        except StopIteration as fin:
-            done[r] = fin.value
-            return
-        for peer, t in req.sends:
-            mailbox[(r, peer)].append(t)
-        waiting[r] = req
+            with torch.inference_mode():
+                out[r] = engines[r].step(batch if not isinstance(batch, list) else batch[r])
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
 
-    for r in range(world):
-        advance(r, first=True)
-    while len(done) < world:
-        progressed = False
-        for r in range(world):
-            req = waiting.get(r)
-            if req is None:
-                continue
-            need = defaultdict(int)
-            for peer, _ in req.recvs:
-                need[peer] += 1
-            if all(len(mailbox[(peer, r)]) >= n for peer, n in need.items()):
-                for peer, dst in req.recvs:
-                    src = mailbox[(peer, r)].popleft()
-                    assert src.shape == dst.shape and src.dtype == dst.dtype
-                    dst.copy_(src)
-                del waiting[r]
-                n_exchanges += 1
-                advance(r)
-                progressed = True
-        assert progressed, "virtual ranks deadlocked"
-    assert all(len(q) == 0 for q in mailbox.values())
-    return [done[r] for r in range(world)], n_exchanges
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    assert all(b.empty() for b in hub.boxes.values())
+    return out, hub.exchanges - before
 
 
 def stitch(bands):
@@ -136,15 +174,14 @@ def test_sharded_rollout_stays_distributed():
         bands1, _ = run_virtual_ranks(model, batch, world)
         dev = batch.crop(model.patch_size).to("cuda")
         nxt = []
+        engines = make_engines(model, world)
         for r, b in enumerate(bands1):
-            model._shard = Shard(r, world, None, gather_output=False)
-            mine = Engine(model).local_band(dev)
-            model._shard = None
+            mine = engines[r].local_band(dev)
             nxt.append(dataclasses.replace(
                 b, surf_vars={k: torch.cat([mine.surf_vars[k][:, 1:], v], dim=1) for k, v in b.surf_vars.items()},
                 atmos_vars={k: torch.cat([mine.atmos_vars[k][:, 1:], v], dim=1) for k, v in b.atmos_vars.items()}))
             assert isinstance(nxt[-1], BandBatch)
-        bands2, _ = run_virtual_ranks(model, nxt, world)
+        bands2, _ = run_virtual_ranks(model, nxt, world, engines)
     surf, atmos = stitch(bands2)
     assert all(b.metadata.rollout_step == 2 for b in bands2)
     for k, v in ref.atmos_vars.items():

@@ -174,21 +174,6 @@ def test_interior_windows_need_no_halo_and_cover_most_of_a_band(res, world, shif
             assert len(interior) >= 0.5 * len(p.tok)   # 8 ranks: 3 (or 2) of the 5 (4) shifted window rows per band
 
 
-def test_fused_layernorm_is_only_picked_when_its_tiles_fill_the_chip():
-    """The row-owning linear + LayerNorm kernel runs one 128-row tile per CU and round: the full 0.25-degree stage 0 fills
-    its rounds, the per-rank bands of a 4- or 8-way split (a few tiles more than one or two rounds) do not."""
-    from aurora_amd.engine.engine import fused_ln_fills
-    from aurora_amd.engine import lib
-
-    assert fused_ln_fills(259200, 256)            # 2025 tiles: 7.9 rounds
-    assert fused_ln_fills(129600, 256)            # two bands: 1013 tiles, 3.96 rounds
-    assert not fused_ln_fills(69120, 256)         # four bands: 540 tiles, 2.1 rounds
-    assert not fused_ln_fills(34560, 256)         # eight bands: 270 tiles, 1.05 rounds
-    assert not fused_ln_fills(16200, 256)         # 127 tiles: half a round
-    assert lib.presplit_ok(2048, 1024) and lib.presplit_ok(512, 160)
-    assert not lib.presplit_ok(80, 1024) and not lib.presplit_ok(512, 48) and not lib.presplit_ok(512, 176)
-
-
 # ---- the C++ twins inside libaurora_hip.so (csrc/band.hip): what the model handle really uses -----------------------
 def _c_rows(n_stages, res0, window, world):
     import ctypes
