@@ -60,7 +60,14 @@ def positive_batch(cfg, H, W, levels):
 
 
 cases = sys.argv[1:] or ["graph", "highres", "airpollution"]
-mem = lambda: round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)  # noqa: E731
+def mem(model=None):
+    """GiB: peak of torch's allocator (inputs, history, weights), the handle's own step workspace (hipMalloc'ed, not seen
+    by torch) and what the device reports as in use right now (everything, incl. the handle's weight copies)."""
+    free, total = torch.cuda.mem_get_info()
+    out = {"torch_peak_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "device_in_use_GiB": round((total - free) / 2 ** 30, 1)}
+    if model is not None:
+        out["handle_workspace_GiB"] = round(model.engine().native.workspace_bytes() / 2 ** 30, 1)
+    return out
 if "graph" in cases:
     model = build(aurora_amd.AuroraPretrained)
     batch = bench.synthetic_batch(model.config, 721, 1440, 1, "cuda")
@@ -72,7 +79,7 @@ if "graph" in cases:
     print(json.dumps({"case": f"configs[2] {n}-step rollout, 0.25deg, 1 GPU", "ms_per_step_eager": eager,
                       "ms_per_step_hipgraph": graphed, "ms_per_step_eager_to_host": eager_host,
                       "ms_per_step_hipgraph_to_host": graphed_host,
-                      "to_host_overhead": graphed_host / graphed - 1.0, "peak_GiB": mem()}), flush=True)
+                      "to_host_overhead": graphed_host / graphed - 1.0, **mem(model)}), flush=True)
     del model, batch
     torch.cuda.empty_cache()
 if "highres" in cases:
@@ -81,7 +88,7 @@ if "highres" in cases:
     batch = bench.synthetic_batch(model.config, 1801, 3600, 1, "cuda")
     ms = timed_rollout(model, batch, 3)
     print(json.dumps({"case": "configs[3] AuroraHighRes 0.1deg 1801x3600 on ONE GPU (LoRA step >= 1)", "ms_per_step": ms,
-                      "peak_GiB": mem()}), flush=True)
+                      **mem(model)}), flush=True)
     del model, batch
     torch.cuda.empty_cache()
 if "airpollution" in cases:
@@ -90,4 +97,4 @@ if "airpollution" in cases:
     batch = positive_batch(model.config, 451, 900, bench.LEVELS)
     ms = timed_rollout(model, batch, 4)
     print(json.dumps({"case": "configs[4] AuroraAirPollution 0.4deg 451x900, 12 h steps, 1 GPU", "ms_per_step": ms,
-                      "peak_GiB": mem()}), flush=True)
+                      **mem(model)}), flush=True)
