@@ -532,8 +532,10 @@ void build_heads(Model& m, HeadGroup& hg, const char* kind, const std::vector<st
   hg.names = names;
   hg.groups = per_level ? m.n_levels : 1;
   if (names.empty()) return;
+  const size_t ldb = (size_t)round_up((int)names.size() * PP, 4);   // per-group bias rows padded: every group stays 16-byte aligned
   hg.w = DevBuf((size_t)hg.groups * names.size() * PP * D2 * 4);
-  hg.b = DevBuf((size_t)hg.groups * names.size() * PP * 4);
+  hg.b = DevBuf((size_t)hg.groups * ldb * 4);
+  hip_ok(hipMemset(hg.b.p, 0, hg.b.bytes), "memset");
   for (int g = 0; g < hg.groups; ++g)
     for (size_t v = 0; v < names.size(); ++v) {
       std::string p = std::string("decoder.") + kind + "_heads." + names[v];
@@ -541,7 +543,7 @@ void build_heads(Model& m, HeadGroup& hg, const char* kind, const std::vector<st
       const Tensor& wt = m.T_(p + ".weight");
       REQUIRE(wt.shape.size() == 2 && wt.shape[0] == PP && wt.shape[1] == D2, "bad head weight shape for %s", p.c_str());
       hip_ok(hipMemcpy(hg.w.f() + ((size_t)g * names.size() + v) * PP * D2, wt.f(), (size_t)PP * D2 * 4, hipMemcpyDeviceToDevice), "copy");
-      hip_ok(hipMemcpy(hg.b.f() + ((size_t)g * names.size() + v) * PP, m.W(p + ".bias"), (size_t)PP * 4, hipMemcpyDeviceToDevice), "copy");
+      hip_ok(hipMemcpy(hg.b.f() + (size_t)g * ldb + v * PP, m.W(p + ".bias"), (size_t)PP * 4, hipMemcpyDeviceToDevice), "copy");
     }
 }
 

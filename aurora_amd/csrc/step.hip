@@ -577,7 +577,7 @@ void run_step(Model& m, const StepIO& s, void* stream) {
       float* y_a = (float*)A.take((size_t)B * Lp * C * ld_a * 4);
       if (hg.groups > 1)   // level c: rows (b L + l) C + c of `lat` -> the same rows of y_a, with that level's head
         L.linear(lat, (int64_t)C * D2, hg.w.f(), D2, hg.b.f(), y_a, (int64_t)C * ld_a, (int64_t)B * Lp, n_a, D2, AURORA_F32, 0, nullptr, 0,
-                 nullptr, 0, -1, nullptr, 0.f, C, D2, (int64_t)n_a * D2, n_a, ld_a);
+                 nullptr, 0, -1, nullptr, 0.f, C, D2, (int64_t)n_a * D2, ld_a, ld_a);
       else
         L.linear(lat, D2, hg.w.f(), D2, hg.b.f(), y_a, ld_a, (int64_t)B * Lp * C, n_a, D2, AURORA_F32);
       std::vector<aurora_unpatch_var> ad;

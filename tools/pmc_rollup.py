@@ -1,7 +1,7 @@
 """Roll the per-kernel PMC summary (tools/pmc_summary.py, written by tools/profile_round.sh) up into the figures
 bench.py and DESIGN.md quote:
 
-    python tools/pmc_rollup.py gpurun_out/r02_pmc_summary.json profiles/r02_pmc_summary.json
+    python tools/pmc_rollup.py gpurun_out/r03_pmc_summary.json profiles/r03_pmc_summary.json $(git rev-parse --short HEAD)
 
   linear_bf16_*  launch-weighted means over the two bf16 GEMM kernels (ring and persistent)
   traffic        = 2 x FETCH_SIZE + WRITE_SIZE: FETCH_SIZE is doubled for the GEMM's LDS-DMA pattern as measured by
@@ -14,6 +14,7 @@ import json
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+build_commit = sys.argv[3] if len(sys.argv) > 3 else None   # commit of the tree the passes profiled (gpurun ships no .git)
 d = json.load(open(src))
 gemm = {k: v for k, v in d.items() if k.startswith("linear_kernel_256p") or k.startswith("linear_kernel_256<unsigned short")}
 n = {k: v["launches"]["fetch"] for k, v in gemm.items()}
@@ -27,6 +28,7 @@ out = {
                     "(profiles/r02_fetch_calibration.txt), so reads = 2 x FETCH_SIZE x 1024 B for every kernel here, the GEMM "
                     "included (round 1 took x1 for the GEMM: wrong).  FETCH_SIZE counts L2 misses on the fabric side: "
                     "Infinity-Cache hits are included, so this is L2-miss traffic, an upper bound of HBM traffic.",
+    "build_commit": build_commit,
     "linear_bf16_launches_profiled": tot,
     "linear_bf16_read_bytes_per_launch": 2.0 * w("FETCH_SIZE_per_launch") * 1024,
     "linear_bf16_write_bytes_per_launch": w("WRITE_SIZE_per_launch") * 1024,
