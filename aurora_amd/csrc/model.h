@@ -221,6 +221,7 @@ struct aurora_hip_model {
   }
   aurora::Arena arena;
   bool dry = false;
+  int64_t generation = 0;   // bumped whenever device memory a captured hipGraph may point at is re-allocated
 
   // optional per-launch timing (aurora_hip_profile_begin / _end): HIP events on the launch stream
   struct Timed { int kind; double work; hipEvent_t e0, e1; };

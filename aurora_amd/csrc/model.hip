@@ -1060,6 +1060,7 @@ extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid
             m.staging_need = std::max(m.staging_need, std::max(pl.send_cnt[side], pl.recv_cnt[side]) * row_bytes);
         }
     m.have_grid = true;
+    m.generation += 1;
   })
 }
 
@@ -1090,6 +1091,7 @@ extern "C" int aurora_hip_set_time_ex(aurora_hip_model* mp, const double* time_h
       m.abs_enc = DevBuf((size_t)B * m.D * 4);
       m.dyn_planes = DevBuf((size_t)6 * B * 4);
       m.abs_B = B;
+      m.generation += 1;
     }
     const size_t n_abs = (size_t)B * m.D, n_dyn = (size_t)6 * m.abs_B, bytes = (n_abs + n_dyn) * 4;
     auto& slot = m.pinned[m.pinned_next++ & 3];
@@ -1163,6 +1165,7 @@ extern "C" int aurora_hip_step(aurora_hip_model* mp, const aurora_hip_step_io* i
       hip_ok(hipMalloc(&p, m.arena.peak), "workspace allocation");
       m.arena.base = (char*)p;
       m.arena.cap = m.arena.peak;
+      m.generation += 1;
     }
     run_step(m, s, stream);
   })
@@ -1202,6 +1205,8 @@ extern "C" int aurora_hip_profile_end(aurora_hip_model* m, aurora_hip_profile_en
     *n_out = K_COUNT;
   })
 }
+
+extern "C" int64_t aurora_hip_generation(const aurora_hip_model* m) { return m ? m->generation : 0; }
 
 extern "C" int aurora_hip_abi_sizes(int32_t* out, int capacity) {
   const int32_t sizes[] = {(int32_t)sizeof(aurora_hip_config), (int32_t)sizeof(aurora_hip_grid), (int32_t)sizeof(aurora_hip_step_io),

@@ -31,10 +31,24 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     const auto& ly = rs.layers[i];
     const int inner = ly.inner, Dd = ly.dim;
     const size_t mark0 = m.arena.top;
-    // result of this layer first (it outlives the temporaries below; stack order)
-    float* y = (float*)m.arena.take((size_t)n_rows * Dd * 4);
+    // Workspace of a layer: three regions instead of one buffer per intermediate (the decoder's intermediates are 3.5 GB each
+    // at 0.25 degree) --
+    //   Y  the layer's result (it outlives the rest; stack order); until fc2 writes it, it holds the attention output
+    //   L  the MLP's input / residual (LayerNorm 1 output)
+    //   S  scratch: k | v (and q), then to_out's result, then the MLP's hidden layer, each dead before the next is written;
+    //      the MLP runs in row chunks so that a chunk's hidden layer fits
+    const size_t unit = (size_t)n_rows * Dd * 4;
+    float* y = (float*)m.arena.take(unit);
     const size_t after_y = m.arena.top;
-    float* kv = (float*)m.arena.take((size_t)ctx_rows * 2 * inner * 4);
+    float* lat1 = (float*)m.arena.take(unit);   // fp32 values, or their fp16 pairs
+    const size_t kv_bytes = (size_t)ctx_rows * 2 * inner * 4, q_bytes = i > 0 ? (size_t)n_rows * inner * 4 : 0;
+    const size_t att_bytes = (size_t)n_rows * inner * 4;
+    const bool att_in_y = att_bytes <= unit;   // (inner <= dim in every published model; else behind everything it coexists with)
+    const size_t kvq_bytes = ((kv_bytes + 255) & ~size_t(255)) + ((q_bytes + 255) & ~size_t(255));
+    const size_t att_off = (std::max(unit, kvq_bytes) + 255) & ~size_t(255);
+    const size_t s_bytes = att_in_y ? std::max(unit, kvq_bytes) : att_off + att_bytes;
+    char* S = (char*)m.arena.take(s_bytes);
+    float* kv = (float*)S;
     // guarded linears with pre-split weights: the two-term launch runs iff the guard holds, the three-term one (fp32
     // weights) iff it does not
     auto guarded = [&](const float* A, int64_t lda, const float* Wf, const void* Ws, float* C_, int64_t ldc, int64_t M_, int N_,
@@ -61,13 +75,13 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     const float* q = q0;
     int64_t q_stride = 0;
     if (i > 0) {
-      float* qb = (float*)m.arena.take((size_t)n_rows * inner * 4);
+      float* qb = (float*)(S + ((kv_bytes + 255) & ~size_t(255)));
       L.linear(lat, Dd, ly.to_q, Dd, nullptr, qb, inner, n_rows, inner, Dd, AURORA_F32);
       if (ly.ln_q_w) L.layernorm(qb, inner, ly.ln_q_w, ly.ln_q_b, nullptr, 0, 0, qb, inner, nullptr, 0, n_rows, inner, 1e-5f, AURORA_F32);
       q = qb;
       q_stride = Lq;
     }
-    float* att = (float*)m.arena.take((size_t)n_rows * inner * 4);
+    float* att = att_in_y ? y : (float*)(S + att_off);
     // |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit.  With pre-split to_out
     // weights the attention writes fp16 pairs iff that guard holds, and to_out multiplies them without splitting anything.
     const float lim_out = (F16_SAFE / ly.v_l1 - g_c) / g_a;
@@ -76,13 +90,12 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
       return aurora_hip_perceiver_attention_ex(q, q_stride, kv, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim,
                                                AURORA_F32, att_pairs ? ctx_max : nullptr, lim_out, L.stream);
     });
-    float* o = (float*)m.arena.take((size_t)n_rows * Dd * 4);
+    float* o = (float*)S;   // (k | v and q are dead)
     guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, lim_out, att_pairs);
     // The MLP in the fp16-pair layout end to end: the LayerNorm writes its result already split (and ONLY split), fc1
     // reads that and writes its GELU'd result split, fc2 reads that -- neither GEMM splits anything -- and the LayerNorm
     // behind the MLP takes the split array as its residual.
     const bool pairs = ly.fc1_s && ly.fc2_s && Dd % 32 == 0;
-    float* lat1 = (float*)m.arena.take((size_t)n_rows * Dd * 4);   // fp32 values, or their fp16 pairs
     {
       const float* res_ = i == 0 ? latents0 : lat;
       const int64_t mod_ = i == 0 ? Lq : 0;
@@ -93,18 +106,28 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
         });
       else L.layernorm(o, Dd, ly.ln1_w, ly.ln1_b, res_, Dd, mod_, lat1, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
     }
-    float* hid = (float*)m.arena.take((size_t)n_rows * ly.hidden * 4);
-    // fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU: bounded whatever the inputs are
-    if (pairs) {
-      const int all = 2 | AURORA_F32_A_SPLIT | AURORA_F32_W_SPLIT;
-      L.linear(lat1, Dd, ly.fc1_s, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
-               nullptr, 0, all | AURORA_F32_C_SPLIT);
-      L.linear(hid, ly.hidden, ly.fc2_s, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0, all);
-    } else {
-      L.linear(lat1, Dd, ly.fc1_w, Dd, ly.fc1_b, hid, ly.hidden, n_rows, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0,
-               nullptr, 0, ly.f16_mode);
-      L.linear(hid, ly.hidden, ly.fc2_w, ly.hidden, ly.fc2_b, y, Dd, n_rows, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0,
-               ly.f16_mode);
+    // fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU: bounded whatever the inputs are.  Row chunks of the
+    // pair fc1 -> fc2, so that the hidden layer of a chunk fits the scratch region (to_out's result is dead by now).
+    float* hid = (float*)S;
+    const size_t hid_row = (size_t)ly.hidden * 4;
+    int64_t chunk_rows = std::min<int64_t>(n_rows, (int64_t)(s_bytes / hid_row));
+    if (chunk_rows < n_rows) chunk_rows = std::max<int64_t>(256, chunk_rows / 256 * 256);   // whole row tiles per chunk
+    REQUIRE((size_t)chunk_rows * hid_row <= s_bytes, "resampler: the scratch region cannot hold 256 hidden rows");
+    for (int64_t r0 = 0; r0 < n_rows; r0 += chunk_rows) {
+      const int64_t nr = std::min(chunk_rows, n_rows - r0);
+      const float* a_ = lat1 + (size_t)r0 * Dd;
+      float* y_ = y + (size_t)r0 * Dd;
+      if (pairs) {
+        const int all = 2 | AURORA_F32_A_SPLIT | AURORA_F32_W_SPLIT;
+        L.linear(a_, Dd, ly.fc1_s, Dd, ly.fc1_b, hid, ly.hidden, nr, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0, nullptr, 0,
+                 all | AURORA_F32_C_SPLIT);
+        L.linear(hid, ly.hidden, ly.fc2_s, ly.hidden, ly.fc2_b, y_, Dd, nr, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0, all);
+      } else {
+        L.linear(a_, Dd, ly.fc1_w, Dd, ly.fc1_b, hid, ly.hidden, nr, ly.hidden, Dd, AURORA_F32, AURORA_ACT_GELU, nullptr, 0, nullptr, 0,
+                 ly.f16_mode);
+        L.linear(hid, ly.hidden, ly.fc2_w, ly.hidden, ly.fc2_b, y_, Dd, nr, Dd, ly.hidden, AURORA_F32, 0, nullptr, 0, nullptr, 0,
+                 ly.f16_mode);
+      }
     }
     if (pairs)
       timed(m, L.stream, K_LAYERNORM, 0.0, [&] {

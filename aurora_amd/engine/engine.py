@@ -252,8 +252,7 @@ class GraphedStep:
         self._addresses = self._handle_addresses()
 
     def _handle_addresses(self):
-        nat = self.engine.native
-        return (nat.workspace_bytes(), nat._grid_key)
+        return self.engine.native.generation()
 
     def advance(self) -> Batch:
         """Replay the graph once: returns the prediction (fresh tensors) and moves the state forward."""

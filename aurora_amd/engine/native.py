@@ -278,6 +278,10 @@ class NativeModel:
     def workspace_bytes(self) -> int:
         return int(lib.load().aurora_hip_workspace_bytes(self._h))
 
+    def generation(self) -> int:
+        """Changes whenever the handle re-allocates device memory a captured hipGraph may point at."""
+        return int(lib.load().aurora_hip_generation(self._h))
+
     # -- the step ---------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, batch: Batch, upload_time: bool = True, out=None) -> Batch:

@@ -55,6 +55,11 @@ def rollout(model, batch: Batch, steps: int, graph: bool = False, to_host: bool 
     The batch is brought to the model's dtype/device once; every prediction stays on the
     device (callers typically `.to("cpu")` what they keep, docs/usage.md:136-141 upstream).
 
+    Aliasing (differs from the reference, whose `torch.cat` copies): a yielded prediction is a VIEW into a history chunk
+    of 8 states that is also the model's next input.  Holding one prediction keeps its whole chunk alive (2.3 GB at 0.25
+    degree against 286 MB for the prediction), and editing a yielded tensor in place changes what later steps read.
+    Callers who keep predictions on the device should `.clone()` them (or move them: `.to("cpu")`, `to_host=True`).
+
     `graph=True` (not in the reference) captures the step as a hipGraph after a warm-up step and
     replays it: one host call per step instead of ~750 kernel launches; the history is shifted inside
     the graph.  A new graph is captured whenever the LoRA weight set / clamping phase of the step changes.

@@ -309,7 +309,8 @@ int aurora_hip_convert(const void* src, void* dst, int64_t n, int src_dtype, voi
  *   aurora_hip_destroy(model)
  *
  * Everything is enqueued on `stream`; a step performs no host synchronisation and may be captured into a hipGraph once
- * one step has run eagerly (the workspace grows on the first step; aurora_hip_set_time stays outside the capture).
+ * one step has run eagerly (the workspace grows on the first step; aurora_hip_set_time stays outside the capture; replay only
+ * while aurora_hip_generation() is unchanged).
  * One in-flight step per handle (the reference's own threading contract, foundry/server/mlflow_wrapper.py:121).
  * The library keeps no state outside the handles.
  */
@@ -416,6 +417,10 @@ int aurora_hip_pos_scale_encoding(const double* lat, const double* lon, int n_la
 int aurora_hip_set_time(aurora_hip_model* model, const double* time_hours, int B, void* stream);
 int aurora_hip_step(aurora_hip_model* model, const aurora_hip_step_io* io, void* stream);
 int64_t aurora_hip_workspace_bytes(const aurora_hip_model* model);
+/* Counts the re-allocations of device memory that enqueued work points at: the workspace (it grows with the first step of
+ * a larger batch / history / grid), the time buffers (a larger batch), the grid tables (aurora_hip_precompute).  A hipGraph
+ * captured from aurora_hip_step is valid for as long as this number does not change. */
+int64_t aurora_hip_generation(const aurora_hip_model* model);
 /* sizeof() of the structs of this header as the library was compiled, in the order aurora_hip_config, aurora_hip_grid,
  * aurora_hip_step_io, aurora_hip_band, aurora_hip_halo_msg, aurora_hip_plan_info, aurora_patch_var, aurora_unpatch_var,
  * aurora_hip_profile_entry: a binding in another language checks its own struct declarations against them.  Returns the

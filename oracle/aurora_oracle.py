@@ -6,10 +6,11 @@ over a flat `state_dict`.  It is the checker that the HIP engine in `aurora_amd/
 compared against; nothing in the product path may import it (only `tests/`,
 `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg do).
 
-Pinning: the oracle is compared against the imported reference itself
-(tests/test_oracle_vs_reference.py, runs where /root/reference exists) and against
-golden input/output vectors that tools/make_golden.py generated from the reference
-(tests/golden/*.npz, checked by tests/test_oracle_golden.py everywhere).
+Pinning: tools/make_golden.py imports the real reference (through tools/ref_stub), runs its
+`rollout()` in fp64 on deterministic weights / inputs (oracle/detdata.py) and stores the outputs as
+tests/golden/*.npz; tests/test_oracle_golden.py checks this file against those vectors everywhere
+(deviation <= 8e-15 where they were made).  tools/time_reference.py additionally compares the two
+on the full 0.25-degree workload where /root/reference exists (7e-7 in fp32).
 
 Everything is written for an arbitrary floating dtype (fp64 for tight checks, fp32
 like-for-like).  `autocast=True` wraps the backbone in `torch.autocast("cpu", bf16)`
