@@ -1055,7 +1055,7 @@ extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid
       for (int s = 0; s < m.n_stages; ++s)
         for (int sh = 0; sh < 2; ++sh) {
           const DevPlan& pl = plan_for(m, s, sh != 0);
-          const int64_t row_bytes = (int64_t)2 * m.stage_dim(s) * (int64_t)m.bbs();
+          const int64_t row_bytes = (int64_t)m.stage_dim(s) * (int64_t)m.bbs();   // the block's input rows travel (step.hip)
           for (int side = 0; side < 2; ++side)
             m.staging_need = std::max(m.staging_need, std::max(pl.send_cnt[side], pl.recv_cnt[side]) * row_bytes);
         }

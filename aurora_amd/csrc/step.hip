@@ -358,14 +358,17 @@ void run_step(Model& m, const StepIO& s, void* stream) {
         REQUIRE(pl.n_own == Ls, "band plan of stage %d holds %d rows, the step %lld", stage, pl.n_own, (long long)Ls);
         const int64_t Lq = Ls + pl.n_halo;
         char* qkv = (char*)A.take((size_t)Lq * 3 * dim * es);
-        L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
         ao = A.take((size_t)M * dim * es);
         const int32_t* tok = (const int32_t*)pl.tok.p;
         const uint8_t* grp = pl.has_grp ? (const uint8_t*)pl.grp.p : nullptr;
-        if (pl.n_halo > 0 || pl.send_cnt[0] > 0 || pl.send_cnt[1] > 0) {
-          // Halo rows travel while the windows that need none of them are attended.  A halo row is only ever a key / value
-          // (its own rank computes its queries), so the k | v columns travel, not q: two thirds of the bytes.
-          const int64_t row_bytes = (int64_t)2 * dim * es;
+        const bool exchange = pl.n_halo > 0 || pl.send_cnt[0] > 0 || pl.send_cnt[1] > 0;
+        if (exchange) {
+          // What travels is the INPUT of the block, not k | v: the halo rows' activations (dim wide: half the bytes of
+          // k | v, a third of q | k | v) leave before this rank's own qkv GEMM is even launched, so the transfer has that
+          // GEMM and the interior windows to hide under; the receiver projects the halo rows to k | v itself (a small GEMM
+          // straight into the halo region of `qkv`: no placement copy).  A halo row is only ever a key / value -- its own
+          // rank computes its queries.
+          const int64_t row_bytes = (int64_t)dim * es;
           aurora_hip_halo_msg sends[2], recvs[2];
           int ns = 0, nr = 0;
           for (int side = 0; side < 2; ++side) {
@@ -373,8 +376,8 @@ void run_step(Model& m, const StepIO& s, void* stream) {
             if (pl.send_cnt[side] > 0) {
               REQUIRE(m.dry || pl.send_cnt[side] * row_bytes <= m.staging_bytes, "band staging buffers are too small");
               timed(m, stream, K_GATHER, 0.0, [&] {
-                return aurora_hip_gather_rows(qkv + (size_t)dim * es, (int64_t)3 * dim * es, (const int32_t*)pl.send_idx[side].p,
-                                              m.stage_send[side], row_bytes, pl.send_cnt[side], row_bytes, stream);
+                return aurora_hip_gather_rows(a_in, row_bytes, (const int32_t*)pl.send_idx[side].p, m.stage_send[side], row_bytes,
+                                              pl.send_cnt[side], row_bytes, stream);
               });
               sends[ns++] = aurora_hip_halo_msg{peer, side, m.stage_send[side], pl.send_cnt[side] * row_bytes};
             }
@@ -387,17 +390,20 @@ void run_step(Model& m, const StepIO& s, void* stream) {
             const int rc = m.band.post(m.band.user, sends, ns, recvs, nr, stream);
             REQUIRE(rc == 0, "the host's halo `post` callback failed (%d)", rc);
           }
+        }
+        L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
+        if (exchange) {
           if (pl.n_interior > 0) attend(qkv, tok, grp, pl.n_interior, pl.n_tok, Lq, Ls);
           if (!m.dry) {
             const int rc = m.band.wait(m.band.user, stream);
             REQUIRE(rc == 0, "the host's halo `wait` callback failed (%d)", rc);
           }
+          // k | v of the received rows: rows [dim, 3 dim) of the qkv weight, written into columns [dim, 3 dim) of the halo rows
+          const char* w_kv = (const char*)aw.qkv[bi] + (size_t)dim * dim * es;
           for (int side = 0; side < 2; ++side)
             if (pl.recv_cnt[side] > 0)
-              timed(m, stream, K_COPY2D, 0.0, [&] {
-                return aurora_hip_copy2d(m.stage_recv[side], 2 * dim, qkv + ((size_t)(Ls + pl.recv_off[side]) * 3 * dim + dim) * es,
-                                         3 * dim, pl.recv_cnt[side], 2 * dim, bb, stream);
-              });
+              L.linear(m.stage_recv[side], dim, w_kv, dim, blk.qkv_b + dim, qkv + ((size_t)(Ls + pl.recv_off[side]) * 3 * dim + dim) * es,
+                       3 * dim, pl.recv_cnt[side], 2 * dim, dim, bb);
           if (pl.n_windows > pl.n_interior)
             attend(qkv, tok + (size_t)pl.n_interior * pl.n_tok, grp ? grp + (size_t)pl.n_interior * pl.n_tok : nullptr,
                    pl.n_windows - pl.n_interior, pl.n_tok, Lq, Ls);

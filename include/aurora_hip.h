@@ -438,10 +438,11 @@ int aurora_hip_set_time_ex(aurora_hip_model* model, const double* time_hours, co
  * single-device) ---------------------------------------------------------------------------------------------------------
  * Every rank owns a contiguous band of latitude rows at every backbone stage (boundaries on the coarsest stage, doubled
  * per finer stage, so patch merges / splits stay local).  Everything except window attention is local to a token, a 2 x 2
- * block or a grid column.  A shifted-window block needs the k | v rows of the neighbouring band's first / last rows: the
- * handle gathers them into `send` staging buffers, calls `post` (start sending / receiving; asynchronous to `stream`),
- * attends the windows that need no halo row, calls `wait` (make `stream` wait for the messages), places the received rows
- * and attends the boundary windows.  The TRANSPORT is the host's: RCCL point-to-point (torch.distributed / ncclSend /
+ * block or a grid column.  A shifted-window block needs k | v of the neighbouring band's first / last rows: the handle
+ * gathers those rows of the block's INPUT into `send` staging buffers (half the bytes of k | v, and available before the
+ * qkv GEMM), calls `post` (start sending / receiving; asynchronous to `stream`), runs its own qkv GEMM and the windows that
+ * need no halo row, calls `wait` (make `stream` wait for the messages), projects the received rows to k | v itself and
+ * attends the boundary windows.  The TRANSPORT is the host's: RCCL point-to-point (torch.distributed / ncclSend /
  * ncclRecv) in production, anything else in tests -- the library does not link a communication library.
  * Message buffers are the four staging buffers the host hands over (its own allocations, so that its transport can
  * address them): to / from the previous rank [0] and the next rank [1], `staging_bytes` each, at least
