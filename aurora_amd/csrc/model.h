@@ -131,7 +131,7 @@ struct HeadGroup {
 struct DevTables { DevBuf tok, grp; int n_windows = 0, n_tok = 0; bool has_grp = false; };
 // The attention plan of one block flavour of a band, on the device (band.h BandPlan).
 struct DevPlan {
-  DevBuf tok, grp, send_idx[2];
+  DevBuf tok, grp, send_idx;   // send_idx: rows for the previous rank, then those for the next
   int n_windows = 0, n_tok = 0, n_own = 0, n_halo = 0, n_interior = 0;
   int recv_off[2] = {0, 0}, recv_cnt[2] = {0, 0}, send_cnt[2] = {0, 0};
   bool has_grp = false;
@@ -200,8 +200,8 @@ struct aurora_hip_model {
   aurora_hip_band band{0, 1, nullptr, nullptr, nullptr};
   std::vector<std::vector<std::array<int, 2>>> rows;         // [stage][rank] owned rows
   std::map<std::pair<int, int>, aurora::DevPlan> plans;      // (stage, shifted)
-  void* stage_send[2] = {nullptr, nullptr};
-  void* stage_recv[2] = {nullptr, nullptr};
+  void* stage_send = nullptr;
+  void* stage_recv = nullptr;
   int64_t staging_bytes = 0, staging_need = 0;
   bool sharded() const { return band.world > 1; }
 

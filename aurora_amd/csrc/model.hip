@@ -379,13 +379,17 @@ const DevPlan& plan_for(Model& m, int stage, bool shifted) {
       d.grp = DevBuf(p.grp.size());
       upload(d.grp.p, p.grp.data(), p.grp.size());
     }
+    std::vector<int32_t> both;
     for (int side = 0; side < 2; ++side) {
       d.recv_off[side] = p.recv_off[side]; d.recv_cnt[side] = p.recv_cnt[side];
       d.send_cnt[side] = (int)p.send_idx[side].size();
-      if (d.send_cnt[side] > 0) {
-        d.send_idx[side] = DevBuf(p.send_idx[side].size() * 4);
-        upload(d.send_idx[side].p, p.send_idx[side].data(), p.send_idx[side].size() * 4);
-      }
+      both.insert(both.end(), p.send_idx[side].begin(), p.send_idx[side].end());
+    }
+    REQUIRE(d.recv_cnt[0] == 0 || d.recv_cnt[1] == 0 || d.recv_off[1] == d.recv_off[0] + d.recv_cnt[0],
+            "band plan: the halo rows of the two neighbours are not adjacent");
+    if (!both.empty()) {
+      d.send_idx = DevBuf(both.size() * 4);
+      upload(d.send_idx.p, both.data(), both.size() * 4);
     }
     it = m.plans.emplace(key, std::move(d)).first;
   }
@@ -882,7 +886,7 @@ extern "C" int aurora_hip_set_band(aurora_hip_model* mp, const aurora_hip_band* 
     }
     m.have_grid = false;   // the grid tables are per band: precompute again
     m.plans.clear(); m.rows.clear();
-    m.stage_send[0] = m.stage_send[1] = m.stage_recv[0] = m.stage_recv[1] = nullptr;
+    m.stage_send = m.stage_recv = nullptr;
     m.staging_bytes = m.staging_need = 0;
   })
 }
@@ -898,17 +902,15 @@ extern "C" int aurora_hip_band_rows(const aurora_hip_model* m, int32_t* row0, in
 
 extern "C" int64_t aurora_hip_band_staging_bytes(const aurora_hip_model* m) { return m ? m->staging_need : 0; }
 
-extern "C" int aurora_hip_set_band_staging(aurora_hip_model* m, void* const send[2], void* const recv[2], int64_t staging_bytes) {
+extern "C" int aurora_hip_set_band_staging(aurora_hip_model* m, void* send, void* recv, int64_t staging_bytes) {
   GUARDED({
-    REQUIRE(m && send && recv, "set_band_staging: null argument");
+    REQUIRE(m != nullptr, "set_band_staging: null model");
     REQUIRE(staging_bytes >= m->staging_need, "set_band_staging: %lld bytes per buffer, %lld needed", (long long)staging_bytes,
             (long long)m->staging_need);
-    for (int s = 0; s < 2; ++s) {
-      REQUIRE(m->staging_need == 0 || (send[s] && recv[s] && (uintptr_t)send[s] % 16 == 0 && (uintptr_t)recv[s] % 16 == 0),
-              "set_band_staging: four 16-byte aligned device buffers are required");
-      m->stage_send[s] = send[s];
-      m->stage_recv[s] = recv[s];
-    }
+    REQUIRE(m->staging_need == 0 || (send && recv && (uintptr_t)send % 16 == 0 && (uintptr_t)recv % 16 == 0),
+            "set_band_staging: two 16-byte aligned device buffers are required");
+    m->stage_send = send;
+    m->stage_recv = recv;
     m->staging_bytes = staging_bytes;
   })
 }
@@ -1056,8 +1058,7 @@ extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid
         for (int sh = 0; sh < 2; ++sh) {
           const DevPlan& pl = plan_for(m, s, sh != 0);
           const int64_t row_bytes = (int64_t)m.stage_dim(s) * (int64_t)m.bbs();   // the block's input rows travel (step.hip)
-          for (int side = 0; side < 2; ++side)
-            m.staging_need = std::max(m.staging_need, std::max(pl.send_cnt[side], pl.recv_cnt[side]) * row_bytes);
+          m.staging_need = std::max(m.staging_need, (int64_t)std::max(pl.send_cnt[0] + pl.send_cnt[1], pl.recv_cnt[0] + pl.recv_cnt[1]) * row_bytes);
         }
     m.have_grid = true;
     m.generation += 1;

@@ -46,7 +46,9 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     const bool att_in_y = att_bytes <= unit;   // (inner <= dim in every published model; else behind everything it coexists with)
     const size_t kvq_bytes = ((kv_bytes + 255) & ~size_t(255)) + ((q_bytes + 255) & ~size_t(255));
     const size_t att_off = (std::max(unit, kvq_bytes) + 255) & ~size_t(255);
-    const size_t s_bytes = att_in_y ? std::max(unit, kvq_bytes) : att_off + att_bytes;
+    const size_t hid_row = (size_t)ly.hidden * 4;
+    const size_t hid_min = (size_t)std::min<int64_t>(n_rows, 256) * hid_row;   // at least one row tile of the hidden layer
+    const size_t s_bytes = std::max(att_in_y ? std::max(unit, kvq_bytes) : att_off + att_bytes, hid_min);
     char* S = (char*)m.arena.take(s_bytes);
     float* kv = (float*)S;
     // guarded linears with pre-split weights: the two-term launch runs iff the guard holds, the three-term one (fp32
@@ -109,10 +111,9 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     // fc1 sees a LayerNorm output (|x| <= sqrt(D) * gain), fc2 its GELU: bounded whatever the inputs are.  Row chunks of the
     // pair fc1 -> fc2, so that the hidden layer of a chunk fits the scratch region (to_out's result is dead by now).
     float* hid = (float*)S;
-    const size_t hid_row = (size_t)ly.hidden * 4;
     int64_t chunk_rows = std::min<int64_t>(n_rows, (int64_t)(s_bytes / hid_row));
-    if (chunk_rows < n_rows) chunk_rows = std::max<int64_t>(256, chunk_rows / 256 * 256);   // whole row tiles per chunk
-    REQUIRE((size_t)chunk_rows * hid_row <= s_bytes, "resampler: the scratch region cannot hold 256 hidden rows");
+    if (chunk_rows < n_rows) chunk_rows = chunk_rows / 256 * 256;   // whole row tiles per chunk (>= 256 rows fit: hid_min)
+    REQUIRE(chunk_rows >= 1 && (size_t)chunk_rows * hid_row <= s_bytes, "resampler: scratch region too small for the MLP");
     for (int64_t r0 = 0; r0 < n_rows; r0 += chunk_rows) {
       const int64_t nr = std::min(chunk_rows, n_rows - r0);
       const float* a_ = lat1 + (size_t)r0 * Dd;
@@ -369,22 +370,22 @@ void run_step(Model& m, const StepIO& s, void* stream) {
           // straight into the halo region of `qkv`: no placement copy).  A halo row is only ever a key / value -- its own
           // rank computes its queries.
           const int64_t row_bytes = (int64_t)dim * es;
+          const int n_send = pl.send_cnt[0] + pl.send_cnt[1], n_recv = pl.recv_cnt[0] + pl.recv_cnt[1];
+          REQUIRE(m.dry || (std::max(n_send, n_recv) * row_bytes <= m.staging_bytes && m.stage_send && m.stage_recv),
+                  "band staging buffers are missing or too small");
+          if (n_send > 0)   // one launch packs the rows for both neighbours: the previous rank's first, the next rank's behind
+            timed(m, stream, K_GATHER, 0.0, [&] {
+              return aurora_hip_gather_rows(a_in, row_bytes, (const int32_t*)pl.send_idx.p, m.stage_send, row_bytes, n_send, row_bytes,
+                                            stream);
+            });
           aurora_hip_halo_msg sends[2], recvs[2];
           int ns = 0, nr = 0;
           for (int side = 0; side < 2; ++side) {
             const int peer = side == 0 ? rank - 1 : rank + 1;
-            if (pl.send_cnt[side] > 0) {
-              REQUIRE(m.dry || pl.send_cnt[side] * row_bytes <= m.staging_bytes, "band staging buffers are too small");
-              timed(m, stream, K_GATHER, 0.0, [&] {
-                return aurora_hip_gather_rows(a_in, row_bytes, (const int32_t*)pl.send_idx[side].p, m.stage_send[side], row_bytes,
-                                              pl.send_cnt[side], row_bytes, stream);
-              });
-              sends[ns++] = aurora_hip_halo_msg{peer, side, m.stage_send[side], pl.send_cnt[side] * row_bytes};
-            }
-            if (pl.recv_cnt[side] > 0) {
-              REQUIRE(m.dry || pl.recv_cnt[side] * row_bytes <= m.staging_bytes, "band staging buffers are too small");
-              recvs[nr++] = aurora_hip_halo_msg{peer, side, m.stage_recv[side], pl.recv_cnt[side] * row_bytes};
-            }
+            if (pl.send_cnt[side] > 0)
+              sends[ns++] = aurora_hip_halo_msg{peer, 0, (side == 0 ? 0 : pl.send_cnt[0]) * row_bytes, pl.send_cnt[side] * row_bytes};
+            if (pl.recv_cnt[side] > 0)
+              recvs[nr++] = aurora_hip_halo_msg{peer, 0, (side == 0 ? 0 : pl.recv_cnt[0]) * row_bytes, pl.recv_cnt[side] * row_bytes};
           }
           if (!m.dry) {
             const int rc = m.band.post(m.band.user, sends, ns, recvs, nr, stream);
@@ -400,10 +401,11 @@ void run_step(Model& m, const StepIO& s, void* stream) {
           }
           // k | v of the received rows: rows [dim, 3 dim) of the qkv weight, written into columns [dim, 3 dim) of the halo rows
           const char* w_kv = (const char*)aw.qkv[bi] + (size_t)dim * dim * es;
-          for (int side = 0; side < 2; ++side)
-            if (pl.recv_cnt[side] > 0)
-              L.linear(m.stage_recv[side], dim, w_kv, dim, blk.qkv_b + dim, qkv + ((size_t)(Ls + pl.recv_off[side]) * 3 * dim + dim) * es,
-                       3 * dim, pl.recv_cnt[side], 2 * dim, dim, bb);
+          const int n_recv = pl.recv_cnt[0] + pl.recv_cnt[1];
+          const int first = pl.recv_cnt[0] > 0 ? pl.recv_off[0] : pl.recv_off[1];   // the two neighbours' halo rows are adjacent
+          if (n_recv > 0)
+            L.linear(m.stage_recv, dim, w_kv, dim, blk.qkv_b + dim, qkv + ((size_t)(Ls + first) * 3 * dim + dim) * es, 3 * dim, n_recv,
+                     2 * dim, dim, bb);
           if (pl.n_windows > pl.n_interior)
             attend(qkv, tok + (size_t)pl.n_interior * pl.n_tok, grp ? grp + (size_t)pl.n_interior * pl.n_tok : nullptr,
                    pl.n_windows - pl.n_interior, pl.n_tok, Lq, Ls);

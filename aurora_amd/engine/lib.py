@@ -527,7 +527,7 @@ class HipConfig(ctypes.Structure):   # aurora_hip_config, field for field
 
 
 class HipHaloMsg(ctypes.Structure):   # aurora_hip_halo_msg
-    _fields_ = [("peer", c_int32), ("side", c_int32), ("data", c_void_p), ("bytes", c_int64)]
+    _fields_ = [("peer", c_int32), ("reserved", c_int32), ("offset", c_int64), ("bytes", c_int64)]
 
 
 HALO_POST_FN = ctypes.CFUNCTYPE(c_int, c_void_p, ctypes.POINTER(HipHaloMsg), c_int32, ctypes.POINTER(HipHaloMsg), c_int32,
@@ -588,7 +588,7 @@ _SIGNATURES.update({
     "aurora_hip_set_band": (c_int, [c_void_p, ctypes.POINTER(HipBand)]),
     "aurora_hip_band_rows": (c_int, [c_void_p, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]),
     "aurora_hip_band_staging_bytes": (c_int64, [c_void_p]),
-    "aurora_hip_set_band_staging": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_int64]),
+    "aurora_hip_set_band_staging": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "aurora_hip_pos_scale_encoding": (c_int, [_PD, _PD, c_int, c_int, c_int, c_int, _PF, _PF]),
     "aurora_hip_band_partition": (c_int, [c_int, ctypes.POINTER(c_int32), ctypes.POINTER(c_int32), c_int, c_int, c_int,
                                           ctypes.POINTER(c_int32), ctypes.POINTER(c_int32)]),

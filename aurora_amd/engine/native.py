@@ -62,8 +62,8 @@ def wave_sources(model) -> tuple[str, ...]:
 class _Transport:
     """Halo transport of a sharded step: the `post` / `wait` callbacks the handle calls (include/aurora_hip.h).
 
-    The four staging buffers are torch tensors (so that torch.distributed can address them); a message is a prefix of
-    one of them.  `post` starts the point-to-point operations of one exchange -- grouped into one ncclGroup on RCCL's
+    The two staging buffers (what is sent, what is received) are torch tensors, so that torch.distributed can address
+    them; a message is a byte range of one of them.  `post` starts the point-to-point operations of one exchange -- grouped into one ncclGroup on RCCL's
     own stream, so the interior windows launched meanwhile overlap the transfer -- and `wait` makes the launch stream
     wait for them (not the host)."""
 
@@ -77,8 +77,8 @@ class _Transport:
 
     def allocate(self, n_bytes: int) -> None:
         n = max(int(n_bytes), 16)
-        self.send = [torch.empty(n, dtype=torch.uint8, device=self.device) for _ in range(2)]
-        self.recv = [torch.empty(n, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.send = torch.empty(n, dtype=torch.uint8, device=self.device)
+        self.recv = torch.empty(n, dtype=torch.uint8, device=self.device)
 
     def _post(self, user, sends, n_sends, recvs, n_recvs, stream) -> int:
         try:
@@ -86,8 +86,9 @@ class _Transport:
 
             sh = self.shard
             to_global = (lambda r: dist.get_global_rank(sh.group, r)) if sh.group is not None else (lambda r: r)
-            out = [(sends[i].peer, self.send[sends[i].side][:sends[i].bytes]) for i in range(n_sends)]
-            inc = [(recvs[i].peer, self.recv[recvs[i].side][:recvs[i].bytes]) for i in range(n_recvs)]
+            cut = lambda buf, m: buf[m.offset:m.offset + m.bytes]  # noqa: E731
+            out = [(sends[i].peer, cut(self.send, sends[i])) for i in range(n_sends)]
+            inc = [(recvs[i].peer, cut(self.recv, recvs[i])) for i in range(n_recvs)]
             if dist.get_backend(sh.group) == "gloo":   # tests: staged through host memory, synchronously
                 host = [(peer, t, torch.empty(t.shape, dtype=t.dtype)) for peer, t in inc]
                 ops = [dist.P2POp(dist.isend, t.cpu(), to_global(peer), sh.group) for peer, t in out]
@@ -244,11 +245,10 @@ class NativeModel:
                 lib._check(L.aurora_hip_band_rows(self._h, ctypes.byref(r0), ctypes.byref(r1)))
                 self.band_rows = (r0.value, r1.value)
                 need = L.aurora_hip_band_staging_bytes(self._h)
-                if self.transport.send is None or self.transport.send[0].numel() < need:
+                if self.transport.send is None or self.transport.send.numel() < need:
                     self.transport.allocate(need)
-                ptrs = lambda ts: (ctypes.c_void_p * 2)(*[t.data_ptr() for t in ts])  # noqa: E731
-                lib._check(L.aurora_hip_set_band_staging(self._h, ptrs(self.transport.send), ptrs(self.transport.recv),
-                                                         self.transport.send[0].numel()))
+                lib._check(L.aurora_hip_set_band_staging(self._h, self.transport.send.data_ptr(), self.transport.recv.data_ptr(),
+                                                         self.transport.send.numel()))
             self._grid_key = key
         self._grid_ident = ident
         self._keep_coords = (lat, lon)

@@ -66,6 +66,9 @@ def synthetic_batch(cfg, H, W, seed, device, levels=LEVELS):
         loc = torch.tensor([nz.locations[f"{k}_{lv}"] for lv in levels])[:, None, None]
         sc = torch.tensor([nz.scales[f"{k}_{lv}"] for lv in levels])[:, None, None]
         atmos[k] = r(1, 2, len(levels), H, W) * sc + loc
+    for d_, names in ((surf, cfg.positive_surf_vars), (atmos, cfg.positive_atmos_vars)):   # (variant models only)
+        for k in names:
+            d_[k] = d_[k].abs()
     md = Metadata(lat=torch.linspace(90, -90, H), lon=torch.linspace(0, 360, W + 1)[:-1],
                   time=(datetime(2020, 6, 1, 12, 0, tzinfo=timezone.utc),), atmos_levels=levels)
     return Batch(surf, static, atmos, md).to(device)
@@ -78,13 +81,13 @@ def log(msg: str) -> None:
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def build_model(device):
+def build_model(device, cls_name: str = "AuroraPretrained"):
     import aurora_amd
 
     torch.manual_seed(0)
     # Build on the GPU: initialising 1.3 B parameters with CPU RNG kernels takes minutes.
     with torch.device(device):
-        model = aurora_amd.AuroraPretrained(autocast=True)
+        model = getattr(aurora_amd, cls_name)(autocast=True)
         with torch.no_grad():
             for p in model.parameters():
                 if not p.any():  # zero-initialised AdaLN modulation: keep the blocks from being no-ops
@@ -108,7 +111,8 @@ def _tmp_dir() -> Path:
     return Path(tempfile.gettempdir())
 
 
-def cpu_worker(budget_s: float, threads: int, weights: str, out_path: str, H: int, W: int) -> None:
+def cpu_worker(budget_s: float, threads: int, weights: str, out_path: str, H: int, W: int,
+               cls_name: str = "AuroraPretrained") -> None:
     """Subprocess body: the CPU oracle (fp32 port of the reference algorithm) on the bench workload -- the weights the
     GPU step used (`weights`: a torch.save'd state_dict) and the same seeded Batch.  A 1/16 sub-grid first (fall-back
     sample), then the full grid, whose outputs go to `out_path` for the parity check.  One JSON object per finished
@@ -119,7 +123,8 @@ def cpu_worker(budget_s: float, threads: int, weights: str, out_path: str, H: in
 
     torch.set_num_threads(threads)
     with torch.device("meta"):
-        cfg = aurora_amd.AuroraPretrained(autocast=True).config
+        meta = getattr(aurora_amd, cls_name)(autocast=True)
+    cfg = meta.config
     sd = torch.load(weights, map_location="cpu", mmap=True, weights_only=True)
     t_start = time.perf_counter()
     Hc = H - H % cfg.patch_size
@@ -131,14 +136,15 @@ def cpu_worker(budget_s: float, threads: int, weights: str, out_path: str, H: in
         t0 = time.perf_counter()
         with torch.inference_mode():
             o_s, o_a, _ = oracle.forward(sd, cfg, b.surf_vars, b.static_vars, b.atmos_vars, b.metadata.lat,
-                                         b.metadata.lon, b.metadata.time, LEVELS, 0, nz.locations, nz.scales)
+                                         b.metadata.lon, b.metadata.time, LEVELS, 0, nz.locations, nz.scales,
+                                         variant=meta.variant)
         dt = time.perf_counter() - t0
         hc = h - h % cfg.patch_size
         frac = (Hc * W) / (hc * w)
         if full:
             torch.save({"surf": {k: v.contiguous() for k, v in o_s.items()},
                         "atmos": {k: v.contiguous() for k, v in o_a.items()}}, out_path)
-            sample = (f"CPU oracle (fp32 port of the reference forward, 1.3B-parameter model, the GPU step's weights and "
+            sample = (f"CPU oracle (fp32 port of the reference forward, {cls_name}, the GPU step's weights and "
                       f"Batch) on the full {hc}x{w} grid: one forward in {dt:.1f} s")
         else:
             sample = (f"CPU oracle on a {hc}x{w} sub-grid = 1/{frac:g} of the tokens in {dt:.2f} s; value = that rate / "
@@ -149,7 +155,7 @@ def cpu_worker(budget_s: float, threads: int, weights: str, out_path: str, H: in
             break   # the full grid would not fit: keep the fall-back sample
 
 
-def cpu_baseline(model, H: int, W: int, budget_s: float) -> tuple[dict, dict | None]:
+def cpu_baseline(model, H: int, W: int, budget_s: float, cls_name: str = "AuroraPretrained") -> tuple[dict, dict | None]:
     """Run `cpu_worker` in a subprocess with a hard timeout (the 256-thread GPU hosts have stalled for minutes inside CPU
     torch ops).  Returns (cpu_baseline object, oracle outputs of the full grid or None)."""
     import subprocess
@@ -161,7 +167,7 @@ def cpu_baseline(model, H: int, W: int, budget_s: float) -> tuple[dict, dict | N
     try:
         torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, wpath)
         cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-worker", "--cpu-budget", str(budget_s - 30),
-               "--cpu-threads", str(threads), "--cpu-weights", str(wpath), "--cpu-out", str(opath), "--grid", f"{H}x{W}"]
+               "--cpu-threads", str(threads), "--cpu-weights", str(wpath), "--cpu-out", str(opath), "--grid", f"{H}x{W}", "--cpu-model", cls_name]
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s,
                                  env={**os.environ, "OMP_NUM_THREADS": str(threads), "HIP_VISIBLE_DEVICES": ""})
@@ -206,7 +212,7 @@ def full_grid_parity(model, batch, pred_bf16, oracle_out: dict) -> dict:
 
     e16 = mean_rel_err(pred_bf16, oracle_out["surf"], oracle_out["atmos"])
     with torch.device("meta"):
-        m32 = aurora_amd.AuroraPretrained(autocast=False)
+        m32 = type(model)(autocast=False)
     m32.load_state_dict(model.state_dict(), assign=True)
     m32 = m32.eval()
     with torch.inference_mode():
@@ -246,10 +252,11 @@ def main() -> None:
     ap.add_argument("--cpu-threads", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-weights", default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-model", default="AuroraPretrained", help=argparse.SUPPRESS)
     args = ap.parse_args()
     GH, GW = map(int, args.grid.split("x"))
     if args.cpu_worker:
-        cpu_worker(args.cpu_budget, args.cpu_threads, args.cpu_weights, args.cpu_out, GH, GW)
+        cpu_worker(args.cpu_budget, args.cpu_threads, args.cpu_weights, args.cpu_out, GH, GW, args.cpu_model)
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

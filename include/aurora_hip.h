@@ -444,15 +444,16 @@ int aurora_hip_set_time_ex(aurora_hip_model* model, const double* time_hours, co
  * need no halo row, calls `wait` (make `stream` wait for the messages), projects the received rows to k | v itself and
  * attends the boundary windows.  The TRANSPORT is the host's: RCCL point-to-point (torch.distributed / ncclSend /
  * ncclRecv) in production, anything else in tests -- the library does not link a communication library.
- * Message buffers are the four staging buffers the host hands over (its own allocations, so that its transport can
- * address them): to / from the previous rank [0] and the next rank [1], `staging_bytes` each, at least
- * aurora_hip_band_staging_bytes() (valid after aurora_hip_precompute).
+ * Message buffers are the two staging buffers the host hands over (its own allocations, so that its transport can address
+ * them): one that the handle fills with what is sent, one that receives; at least aurora_hip_band_staging_bytes() each
+ * (valid after aurora_hip_precompute).  A message is a byte range of one of them: what goes to / comes from the previous
+ * rank first, the next rank's behind it -- so one gather launch packs both and one GEMM projects both.
  * Call order: create, pack, finalize, aurora_hip_set_band, aurora_hip_precompute with the FULL grid, aurora_hip_band_rows,
  * aurora_hip_set_band_staging, then steps on the band's rows. */
 typedef struct aurora_hip_halo_msg {
   int32_t peer;       /* rank */
-  int32_t side;       /* 0: the previous rank's staging buffer, 1: the next rank's */
-  void* data;         /* device pointer inside that staging buffer */
+  int32_t reserved;
+  int64_t offset;     /* byte offset into the send (for a send) or the receive (for a receive) staging buffer */
   int64_t bytes;
 } aurora_hip_halo_msg;
 typedef int (*aurora_hip_halo_post_fn)(void* user, const aurora_hip_halo_msg* sends, int32_t n_sends,
@@ -468,7 +469,7 @@ int aurora_hip_set_band(aurora_hip_model* model, const aurora_hip_band* band);  
 /* Data rows [row0, row1) of the full (cropped) latitude axis that this rank owns. */
 int aurora_hip_band_rows(const aurora_hip_model* model, int32_t* row0, int32_t* row1);
 int64_t aurora_hip_band_staging_bytes(const aurora_hip_model* model);
-int aurora_hip_set_band_staging(aurora_hip_model* model, void* const send[2], void* const recv[2], int64_t staging_bytes);
+int aurora_hip_set_band_staging(aurora_hip_model* model, void* send, void* recv, int64_t staging_bytes);
 /* The partition and the attention plans themselves, as pure host functions (no model, no device work): what the handle
  * uses internally, exposed for hosts that place data themselves and for tests (tests/test_partition.py compares them with
  * numpy plans that are replayed against global attention).

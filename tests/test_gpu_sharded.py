@@ -38,11 +38,11 @@ class VirtualTransport(native._Transport):
         try:
             for i in range(n_sends):
                 m = sends[i]
-                assert abs(m.peer - self.rank) == 1 and m.side == (0 if m.peer < self.rank else 1)
+                assert abs(m.peer - self.rank) == 1
                 consumed = threading.Event()
-                self.hub.box(self.rank, m.peer).put((self.send[m.side][:m.bytes], consumed))
+                self.hub.box(self.rank, m.peer).put((self.send[m.offset:m.offset + m.bytes], consumed))
                 self.sent.append(consumed)
-            self.expect = [(recvs[i].peer, recvs[i].side, recvs[i].bytes) for i in range(n_recvs)]
+            self.expect = [(recvs[i].peer, recvs[i].offset, recvs[i].bytes) for i in range(n_recvs)]
             self.hub.exchanges += 1
             return 0
         except BaseException as e:  # noqa: BLE001
@@ -51,10 +51,10 @@ class VirtualTransport(native._Transport):
 
     def _wait(self, user, stream) -> int:
         try:
-            for peer, side, n_bytes in self.expect:
+            for peer, offset, n_bytes in self.expect:
                 src, consumed = self.hub.box(peer, self.rank).get(timeout=self.TIMEOUT)
                 assert src.numel() == n_bytes, (src.numel(), n_bytes)
-                self.recv[side][:n_bytes].copy_(src)
+                self.recv[offset:offset + n_bytes].copy_(src)
                 consumed.set()
             for consumed in self.sent:
                 assert consumed.wait(self.TIMEOUT), "a halo message was never received"
