@@ -127,10 +127,13 @@ def cpu_worker(budget_s: float, threads: int, weights: str, out_path: str, H: in
     cfg = meta.config
     sd = torch.load(weights, map_location="cpu", mmap=True, weights_only=True)
     t_start = time.perf_counter()
-    Hc = H - H % cfg.patch_size
-    samples = [(Hc // 4 - (Hc // 4) % cfg.patch_size, W // 4 - (W // 4) % cfg.patch_size, False), (H, W, True)]
+    P = cfg.patch_size
+    Hc = H - H % P
+    # fall-back sample: a quarter of the rows / columns, an EVEN number of patch rows (with an odd number the middle
+    # patch's mean latitude is a rounding residue of 0, outside the position encoding's range; encoder.py / fourier.py:64-72)
+    samples = [((Hc // 4) // (2 * P) * 2 * P, (W // 4) // P * P, False), (H, W, True)]
     for (h, w, full) in samples:
-        if h < cfg.patch_size or w < cfg.patch_size or (not full and (h, w) == (Hc, W)):
+        if h < 2 * P or w < P or (not full and (h, w) == (Hc, W)):
             continue
         b = synthetic_batch(cfg, h, w, 1, "cpu")
         t0 = time.perf_counter()
