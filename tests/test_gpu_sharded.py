@@ -198,7 +198,7 @@ def test_gather_rows_and_band_output_limit():
     assert torch.equal(out, src[idx.long()])
 
 
-def _proc(rank, world, port, ret):
+def _proc(rank, world, port, ret, tmp):
     import os
 
     import torch.distributed as dist
@@ -213,8 +213,17 @@ def _proc(rank, world, port, ret):
         full = model.forward(batch)                       # every rank gets the whole prediction
         model.configure_sharding(rank, world, gather_output=False)
         preds = list(aurora_amd.rollout(model, batch, steps=2))  # state stays distributed
+        # sharded output: every rank writes ITS band of every step, nothing is gathered
+        paths = aurora_amd.write_rollout(model, batch, 2, os.path.join(tmp, "pred.{step}.{rank:02d}.nc"))
     torch.cuda.synchronize()
     assert isinstance(preds[1], BandBatch) and preds[1].metadata.rollout_step == 2
+    assert [os.path.basename(p_) for p_ in paths] == [f"pred.{s_}.{rank:02d}.nc" for s_ in (1, 2)]
+    dist.barrier()
+    if rank == 0:   # the per-rank files of step 1 reassemble to the un-sharded prediction
+        joined = Batch.from_netcdf(os.path.join(tmp, "pred.1.{rank:02d}.nc"))
+        assert joined.spatial_shape == ref.spatial_shape
+        for k, v in ref.atmos_vars.items():
+            assert helpers.rel_err(joined.atmos_vars[k], v.cpu()) < 2e-6, k
     if rank == 0:
         err = max(helpers.rel_err(full.atmos_vars[k].cpu(), v.cpu()) for k, v in ref.atmos_vars.items())
         err = max(err, max(helpers.rel_err(full.surf_vars[k].cpu(), v.cpu()) for k, v in ref.surf_vars.items()))
@@ -228,7 +237,7 @@ def _proc(rank, world, port, ret):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_multiprocess_sharding_on_one_gpu(world):
+def test_multiprocess_sharding_on_one_gpu(world, tmp_path):
     """The production code path (configure_sharding + forward / rollout, torch.distributed P2P halo
     exchange, broadcast gather) with real processes; transport = gloo with host staging because
     several ranks share this box's single GPU (RCCL needs one GPU per rank)."""
@@ -236,7 +245,7 @@ def test_multiprocess_sharding_on_one_gpu(world):
 
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_proc, args=(r, world, 29700 + world, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_proc, args=(r, world, 29700 + world, ret, str(tmp_path))) for r in range(world)]
     for p_ in procs:
         p_.start()
     for p_ in procs:
