@@ -175,6 +175,28 @@ def test_graph_captured_rollout_equals_eager(name, autocast):
     assert not torch.equal(graphed[0].surf_vars["2t"], graphed[1].surf_vars["2t"])
 
 
+def test_captured_graph_refuses_to_replay_after_the_handle_reallocated():
+    """A hipGraph of the step bakes in the addresses of the handle's workspace and tables.  Running the same model eagerly on
+    a larger batch re-allocates them (`aurora_hip_generation` changes): `advance()` must refuse instead of replaying into
+    freed memory, and `rollout(graph=True)` must capture anew by itself."""
+    case, model, batch = build("base_pad")
+    with torch.inference_mode():
+        stepper = model.engine().capture(batch)
+        first = stepper.advance()
+        gen = model.engine().native.generation()
+        two = dataclasses.replace(
+            batch, surf_vars={k: v.repeat(2, 1, 1, 1) for k, v in batch.surf_vars.items()},
+            atmos_vars={k: v.repeat(2, 1, 1, 1, 1) for k, v in batch.atmos_vars.items()},
+            metadata=dataclasses.replace(batch.metadata, time=batch.metadata.time * 2))
+        model.forward(two)                                   # B = 2: larger workspace, larger time buffers
+        assert model.engine().native.generation() != gen
+        with pytest.raises(RuntimeError, match="capture a new graph"):
+            stepper.advance()
+        again = next(iter(rollout(model, batch, steps=1, graph=True)))
+    for k, v in first.surf_vars.items():
+        assert torch.equal(again.surf_vars[k], v), k
+
+
 def test_rollout_history_windows_equal_the_reference_cat_loop():
     """`rollout` slides a window over history chunks and lets the model write each prediction into the next slot; the
     reference's loop (rollout.py:39-49: forward, then `cat([old[:, 1:], pred])`) must give the same states, across a
