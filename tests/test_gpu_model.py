@@ -254,3 +254,26 @@ def test_write_rollout_files_equal_the_predictions(tmp_path):
         for d, rd in ((got.surf_vars, ref.surf_vars), (got.atmos_vars, ref.atmos_vars)):
             for k, v in rd.items():
                 assert torch.equal(d[k], v), k
+
+
+def test_a_subset_of_the_variables_runs_like_the_reference():
+    """The reference accepts a Batch that carries only some of the model's variables (every variable has its own patch
+    embedding weight and head, patchembed.py:100-115, decoder.py:214-263).  Through the C ABI an absent variable is a NULL
+    entry of the pointer lists: the embedding GEMM is packed for the present channels, only they are predicted."""
+    case, model, batch = build("base_pad")
+    drop_s, drop_a = "msl", "q"
+    sub = dataclasses.replace(batch, surf_vars={k: v for k, v in batch.surf_vars.items() if k != drop_s},
+                              atmos_vars={k: v for k, v in batch.atmos_vars.items() if k != drop_a})
+    sd = helpers.case_state_dict(model, torch.float32)
+    with torch.inference_mode():
+        pred = model.forward(sub)
+        o_s, o_a, _ = oracle.forward(sd, model.config, {k: v.cpu() for k, v in sub.surf_vars.items()},
+                                     {k: v.cpu() for k, v in sub.static_vars.items()},
+                                     {k: v.cpu() for k, v in sub.atmos_vars.items()}, sub.metadata.lat.cpu(), sub.metadata.lon.cpu(),
+                                     sub.metadata.time, case["levels"], 0, normalisation.locations, normalisation.scales)
+    assert list(pred.surf_vars) == list(sub.surf_vars) and list(pred.atmos_vars) == list(sub.atmos_vars)
+    for d, od in ((pred.surf_vars, o_s), (pred.atmos_vars, o_a)):
+        for k, v in d.items():
+            assert helpers.mean_rel_err(v.cpu(), od[k]) <= 1e-4, k
+    with pytest.raises(KeyError):
+        model.forward(dataclasses.replace(batch, surf_vars={**batch.surf_vars, "sst": batch.surf_vars["2t"]}))
