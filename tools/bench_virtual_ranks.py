@@ -1,10 +1,14 @@
-"""Compute-side cost of latitude-band sharding, measured on ONE GPU: the R ranks of a sharded 0.25-degree step are
-run as virtual ranks in one process (tests/test_gpu_sharded.py harness; halo rows copied device-to-device), so the
-total GPU time is the SUM of the per-rank compute.  sum / R is what one rank of an R-GPU job computes per step
-(communication excluded); (un-sharded step) / sum is the compute efficiency of the partition (halo recomputation,
-thin GEMMs, tile quantisation).
+"""Compute-side cost of latitude-band sharding, measured on ONE GPU: each of the R ranks of a sharded 0.25-degree step is
+run ALONE (its handle, its band of the inputs; the halo transport is a no-op that leaves zeros in the receive buffer, so
+the rank does exactly the work it would do -- gather, qkv GEMM, halo projection, interior / boundary windows -- on halo
+values that do not matter for timing).  sum over ranks = the GPU time of the whole sharded step without communication;
+(un-sharded step) / sum is the compute efficiency of the partition (halo work, thin GEMMs, tile quantisation);
+max over ranks is what bounds a real R-GPU step from below.
 
     python tools/bench_virtual_ranks.py [R ...]      (default 2 4 8)
+
+(tests/test_gpu_sharded.py runs the ranks TOGETHER, one thread each, with real halo copies: that checks results; its wall
+time includes the threads' waiting for each other and is not a compute measurement.)
 """
 import json
 import sys
@@ -16,14 +20,26 @@ import torch
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402
-from tests.test_gpu_sharded import make_engines, run_virtual_ranks  # noqa: E402
-
-model = bench.build_model("cuda")
-batch = bench.synthetic_batch(model.config, 721, 1440, 1, "cuda").crop(model.patch_size)
+from aurora_amd.engine import native  # noqa: E402
+from aurora_amd.engine.engine import Engine, Shard  # noqa: E402
 
 
-def timed(fn, n=3):
+class NoTransport(native._Transport):
+    def allocate(self, n_bytes):
+        super().allocate(n_bytes)
+        self.send.zero_()
+        self.recv.zero_()
+
+    def _post(self, *a):
+        return 0
+
+    def _wait(self, *a):
+        return 0
+
+
+def timed(fn, n=4):
     with torch.inference_mode():
+        fn()
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -33,11 +49,21 @@ def timed(fn, n=3):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+model = bench.build_model("cuda")
+batch = bench.synthetic_batch(model.config, 721, 1440, 1, "cuda").crop(model.patch_size)
 single = timed(lambda: model.forward(batch))
 print(json.dumps({"ranks": 1, "ms_per_step": single}), flush=True)
 for R in [int(a) for a in sys.argv[1:]] or [2, 4, 8]:
-    engines = make_engines(model, R)
-    total = timed(lambda: run_virtual_ranks(model, batch, R, engines), n=2)
-    del engines
-    print(json.dumps({"ranks": R, "sum_of_rank_compute_ms": total, "per_rank_ms": total / R,
-                      "compute_efficiency": single / total}), flush=True)
+    per_rank = []
+    for r in range(R):
+        model._shard = Shard(r, R, None, gather_output=False)
+        eng = Engine(model, transport=NoTransport(None, "cuda"))
+        model._shard = None
+        band = eng.local_band(batch)
+        per_rank.append(timed(lambda: eng.step(band)))
+        del eng, band
+        torch.cuda.empty_cache()
+    total = sum(per_rank)
+    print(json.dumps({"ranks": R, "per_rank_ms": [round(x, 2) for x in per_rank], "sum_of_rank_compute_ms": total,
+                      "max_rank_ms": max(per_rank), "compute_efficiency": single / total,
+                      "strong_scaling_bound_without_communication": single / (R * max(per_rank))}), flush=True)
