@@ -91,8 +91,8 @@ extern "C" int aurora_hip_version(void) { return 1; }
 
 namespace aurora {
 namespace {
-// max |x| over a contiguous fp32 array: 16-byte loads, wave reduction, one atomic per wave (non-negative floats order
-// like their bit patterns).  NaN compares false everywhere and is ignored; +-inf wins.
+// max |x| over a contiguous fp32 array: 16-byte loads, wave + block reduction, at most one atomic per block (non-negative
+// floats order like their bit patterns).  NaN compares false everywhere and is ignored; +-inf wins.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, float* out) {
   float m = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -101,8 +101,18 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
+  // One atomic per BLOCK, and only if it can still raise the word: 8192 same-address atomics (one per wave of 2048 blocks)
+  // serialise at ~12 ns each -- a fixed ~100 us per launch, more than the scan of a latitude band's inputs takes.
+  __shared__ float part[4];
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    const unsigned int bits = __float_as_uint(m);
+    if (bits > __hip_atomic_load(reinterpret_cast<unsigned int*>(out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<unsigned int*>(out), bits);
+  }
 }
 }  // namespace
 }  // namespace aurora

@@ -565,3 +565,19 @@ def test_convert_and_copy2d():
     L.copy2d(src, dst[:, 64:])
     torch.cuda.synchronize()
     assert torch.equal(dst[:, 64:], src) and (dst[:, :64] == 0).all()
+
+
+@pytest.mark.parametrize("n", [4, 1000, 4097, 3_000_001])
+def test_absmax_ignores_nan_and_finds_the_largest_magnitude(n):
+    from aurora_amd.engine import lib as L
+
+    g = torch.Generator(device="cuda").manual_seed(n)
+    x = torch.randn(n, device="cuda", generator=g)
+    x[n // 3] = -123.5
+    if n > 8:
+        x[n - 2] = float("nan")
+    out = L.absmax(x)
+    torch.cuda.synchronize()
+    assert out.item() == 123.5
+    x[0] = float("-inf")
+    assert L.absmax(x).item() == float("inf")
