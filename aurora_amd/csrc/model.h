@@ -124,8 +124,12 @@ struct EmbedPack {
 // A surface / atmospheric output variable and the head columns it is decoded from (embed.hip unpatchify).
 struct HeadGroup {
   std::vector<std::string> names;      // head names in column order (variables, then `<v>_mod`)
-  DevBuf w, b;                         // [groups][n * P * P][2D], [groups][n * P * P]
+  DevBuf w, b;                         // [groups][n * P * P][2D], [groups][round_up(n * P * P, 4)]
   int groups = 1;
+  // the same heads for the two-term fp16 GEMM (when the weights allow): rows zero-padded to a multiple of 256 -- the tile
+  // width of linear_kernel_f32pp --, weights in the fp16-pair layout scaled by 2^6, bias rows padded likewise
+  DevBuf ws, bs;                       // [groups][n_pad][2D] pairs, [groups][n_pad]
+  int n_pad = 0;                       // 0: not available
 };
 
 struct DevTables { DevBuf tok, grp; int n_windows = 0, n_tok = 0; bool has_grp = false; };
@@ -192,6 +196,7 @@ struct aurora_hip_model {
   float surf_l1_0 = 0.f, surf_b0 = 0.f, surf_c = 0.f;
   bool surf_chain = false;
   aurora::HeadGroup head_surf, head_main, head_alt;
+  float dec_out_bound = 0.f, dec_out_bound_alt = 0.f;   // |output of the decoder Perceiver(s)| <= this (LayerNorm bounds + queries)
   std::map<std::pair<int, int>, aurora::DevTables> tables;   // (stage, shifted)
   std::vector<aurora::Res> stage_res;                        // token grids of the WHOLE forecast
   std::vector<std::array<int, 2>> merge_pad;                 // (pad_h, pad_w) after each stage (whole grid)

@@ -549,6 +549,29 @@ void build_heads(Model& m, HeadGroup& hg, const char* kind, const std::vector<st
       hip_ok(hipMemcpy(hg.w.f() + ((size_t)g * names.size() + v) * PP * D2, wt.f(), (size_t)PP * D2 * 4, hipMemcpyDeviceToDevice), "copy");
       hip_ok(hipMemcpy(hg.b.f() + (size_t)g * ldb + v * PP, m.W(p + ".bias"), (size_t)PP * 4, hipMemcpyDeviceToDevice), "copy");
     }
+  // ---- the two-term form: N padded to the 256-column tiles of the fp16-pair GEMM (zero rows cost MFMAs, not bytes of A) ----
+  hg.n_pad = 0;
+  hg.ws = DevBuf(); hg.bs = DevBuf();
+  if (std::string(kind) != "atmos" || bounded_mode() != 2 || D2 % 32 != 0 || D2 < 96) return;
+  const int n = (int)names.size() * PP, n_pad = round_up(n, 256);
+  std::vector<float> hw((size_t)hg.groups * n * D2);
+  hip_ok(hipMemcpy(hw.data(), hg.w.p, hw.size() * 4, hipMemcpyDeviceToHost), "download");
+  float wmax = 0.f;
+  for (float v : hw) wmax = std::max(wmax, fabsf(v));
+  if (!(wmax < 1000.f)) return;
+  DevBuf padded((size_t)hg.groups * n_pad * D2 * 4);
+  hip_ok(hipMemset(padded.p, 0, padded.bytes), "memset");
+  hg.bs = DevBuf((size_t)hg.groups * n_pad * 4);
+  hip_ok(hipMemset(hg.bs.p, 0, hg.bs.bytes), "memset");
+  for (int g = 0; g < hg.groups; ++g) {
+    hip_ok(hipMemcpy(padded.f() + (size_t)g * n_pad * D2, hg.w.f() + (size_t)g * n * D2, (size_t)n * D2 * 4, hipMemcpyDeviceToDevice), "copy");
+    hip_ok(hipMemcpy(hg.bs.f() + (size_t)g * n_pad, hg.b.f() + (size_t)g * ldb, (size_t)n * 4, hipMemcpyDeviceToDevice), "copy");
+  }
+  hg.ws = DevBuf(padded.bytes);
+  if (aurora_hip_split_f16(padded.f(), D2, hg.ws.p, D2, (int64_t)hg.groups * n_pad, D2, 64.0f, nullptr) != AURORA_OK)
+    throw std::runtime_error(aurora_hip_last_error());
+  hip_ok(hipDeviceSynchronize(), "split head weights");
+  hg.n_pad = n_pad;
 }
 
 }  // namespace
@@ -1005,6 +1028,32 @@ extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid
       first_q(m.dec_rs, m.dec_q);
       if (m.has_alt) first_q(m.dec_rs_alt, m.dec_q_alt);
       hip_ok(hipStreamSynchronize(as_stream(stream)), "precompute sync");
+      // What a decoder Perceiver can put out, whatever the inputs: every layer returns LN2(.) + LN1(.) + its residual, the
+      // first residual being the level queries -- |LN(x) g + b| <= sqrt(D) max|g| + max|b|.  Decides whether the output may
+      // leave in the fp16-pair layout for the output heads' two-term GEMM (step.hip).
+      {
+        std::vector<float> q((size_t)C * 2 * D);
+        hip_ok(hipMemcpy(q.data(), m.dec_queries.p, q.size() * 4, hipMemcpyDeviceToHost), "download");
+        float qmax = 0.f;
+        for (float v : q) qmax = std::max(qmax, fabsf(v));
+        auto amax = [&](const float* dev, size_t n) {
+          std::vector<float> h(n);
+          hip_ok(hipMemcpy(h.data(), dev, n * 4, hipMemcpyDeviceToHost), "download");
+          float mx = 0.f;
+          for (float v : h) mx = std::max(mx, fabsf(v));
+          return mx;
+        };
+        auto bound_of = [&](const Resampler& rs) {
+          float b = qmax;
+          for (const auto& ly : rs.layers) {
+            const float rt = sqrtf((float)ly.dim);
+            b += amax(ly.ln1_w, ly.dim) * rt + amax(ly.ln1_b, ly.dim) + amax(ly.ln2_w, ly.dim) * rt + amax(ly.ln2_b, ly.dim);
+          }
+          return b;
+        };
+        m.dec_out_bound = bound_of(m.dec_rs);
+        m.dec_out_bound_alt = m.has_alt ? bound_of(m.dec_rs_alt) : 0.f;
+      }
       std::vector<float> eb((size_t)C * D);
       hip_ok(hipMemcpy(eb.data(), m.enc_bias.p, eb.size() * 4, hipMemcpyDeviceToHost), "download");
       m.enc_bias_max = 0.f;

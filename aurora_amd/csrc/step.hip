@@ -17,7 +17,7 @@ struct CtxGuard { const float* word; float a, c, limit_kv; bool pairs; };
 // b*kv_bstride + j*kv_lstride + l.  First layer: latents (and so q) are shared by every column.  Returns (B*cols*Lq, D).
 float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, int64_t ctx_rows, int ctx_dim, const float* q0,
                  const float* latents0, int B, int64_t cols, int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads,
-                 float eps, size_t& out_mark, const CtxGuard* cg = nullptr) {
+                 float eps, size_t& out_mark, const CtxGuard* cg = nullptr, bool out_pairs = false) {
   const int64_t n_rows = (int64_t)B * cols * Lq;
   // The context is as unbounded as the model inputs, so the linears that read it, or averages of its value projection,
   // pick their operand split on the device: from max |ctx|, measured here, or from the bound the caller derived from a
@@ -130,9 +130,13 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
                  ly.f16_mode);
       }
     }
+    // (`out_pairs`: the LAST layer's result leaves in the fp16-pair layout, in place -- a row is in registers before any of
+    // it is written --, for a consumer that multiplies it without splitting anything: the decoder's output heads)
+    const bool y_pairs = out_pairs && pairs && i + 1 == rs.layers.size();
     if (pairs)
       timed(m, L.stream, K_LAYERNORM, 0.0, [&] {
-        return aurora_hip_layernorm_split(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, 1, y, Dd, nullptr, 0, n_rows, Dd, eps, L.stream);
+        return aurora_hip_layernorm_split(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, 1, y_pairs ? nullptr : y, Dd, y_pairs ? y : nullptr, Dd,
+                                          n_rows, Dd, eps, L.stream);
       });
     else L.layernorm(y, Dd, ly.ln2_w, ly.ln2_b, lat1, Dd, 0, y, Dd, nullptr, 0, n_rows, Dd, eps, AURORA_F32);
     m.arena.top = after_y;            // temporaries of this layer are dead (a previous layer's result stays below y)
@@ -601,16 +605,27 @@ void run_step(Model& m, const StepIO& s, void* stream) {
       const HeadGroup& hg = *groups[gi].h;
       if (hg.names.empty()) continue;
       const size_t gmark = A.top;
+      // The output heads have few columns (80 at patch size 4, 500 at 10): on the native-fp32 128 x 128 kernel they ran at
+      // 77 TFLOP/s.  When the Perceiver's output is bounded inside fp16's range by its LayerNorm parameters alone (it is: a few
+      // hundred), its last LayerNorm writes fp16 pairs and the heads -- rows zero-padded to the 256-column tile, weights
+      // pre-split -- run on the VALU-free two-term kernel instead.
+      const Resampler& rs = *groups[gi].rs;
+      const auto& last_ly = rs.layers.back();
+      const bool last_pairs = last_ly.fc1_s && last_ly.fc2_s && last_ly.dim % 32 == 0;
+      const bool two_term = hg.n_pad > 0 && last_pairs && (gi == 0 ? m.dec_out_bound : m.dec_out_bound_alt) < F16_SAFE;
       size_t rs_mark = 0;
-      float* lat = resampler(m, L, *groups[gi].rs, ctx, (int64_t)B * (Cl - 1) * Lp, D2, groups[gi].q, m.dec_queries.f(), B, Lp,
-                             (int64_t)(Cl - 1) * Lp, Lp, C, Cl - 1, m.perceiver_heads, m.ln_eps, rs_mark);
-      const int n_a = (int)hg.names.size() * PP, ld_a = round_up(n_a, 4);
+      float* lat = resampler(m, L, rs, ctx, (int64_t)B * (Cl - 1) * Lp, D2, groups[gi].q, m.dec_queries.f(), B, Lp,
+                             (int64_t)(Cl - 1) * Lp, Lp, C, Cl - 1, m.perceiver_heads, m.ln_eps, rs_mark, nullptr, two_term);
+      const int n_a = two_term ? hg.n_pad : (int)hg.names.size() * PP, ld_a = round_up(n_a, 4);
+      const float* hw = two_term ? (const float*)hg.ws.p : hg.w.f();
+      const float* hb = two_term ? hg.bs.f() : hg.b.f();
+      const int mode = two_term ? (2 | AURORA_F32_A_SPLIT | AURORA_F32_W_SPLIT) : -1;
       float* y_a = (float*)A.take((size_t)B * Lp * C * ld_a * 4);
       if (hg.groups > 1)   // level c: rows (b L + l) C + c of `lat` -> the same rows of y_a, with that level's head
-        L.linear(lat, (int64_t)C * D2, hg.w.f(), D2, hg.b.f(), y_a, (int64_t)C * ld_a, (int64_t)B * Lp, n_a, D2, AURORA_F32, 0, nullptr, 0,
-                 nullptr, 0, -1, nullptr, 0.f, C, D2, (int64_t)n_a * D2, ld_a, ld_a);
+        L.linear(lat, (int64_t)C * D2, hw, D2, hb, y_a, (int64_t)C * ld_a, (int64_t)B * Lp, n_a, D2, AURORA_F32, 0, nullptr, 0,
+                 nullptr, 0, mode, nullptr, 0.f, C, D2, (int64_t)n_a * D2, ld_a, ld_a);
       else
-        L.linear(lat, D2, hg.w.f(), D2, hg.b.f(), y_a, ld_a, (int64_t)B * Lp * C, n_a, D2, AURORA_F32);
+        L.linear(lat, D2, hw, D2, hb, y_a, ld_a, (int64_t)B * Lp * C, n_a, D2, AURORA_F32, 0, nullptr, 0, nullptr, 0, mode);
       std::vector<aurora_unpatch_var> ad;
       for (size_t hi = 0; hi < hg.names.size(); ++hi) {
         const std::string& name = hg.names[hi];
