@@ -47,8 +47,9 @@ __device__ __forceinline__ float patch_transform(float z, const PatchVar& d) {
   return z;
 }
 
-template <typename T>
+// Patch size 4, fp32, every piece 16-byte aligned (the 0.25-degree models):
 __global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
+  typedef float T;
   // item = (row, q) with q = (v*T + t)*P + i fastest: neighbouring threads fill one output row.
   const int L = p.Hp * p.Wp;
   const int64_t rows = (int64_t)p.n_lvl * p.B * L;
@@ -68,22 +69,48 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
   const float loc = d.loc[c], inv = d.inv_scale[c];
   const float* src = d.src + b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)(wp * p.P) * d.sw;
   T* dst = reinterpret_cast<T*>(p.out) + row * p.Kpad + p.k_offset + (int64_t)vt * p.P * p.P + i * p.P;
-  if (p.P == 4 && d.sw == 1 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0 && sizeof(T) == 4) {
-    // patch size 4, fp32 operand (the encoder): one 16-byte load and one 16-byte store per thread
+  {
+    // patch size 4, fp32 operand, aligned (checked by the launcher): one 16-byte load and one 16-byte store per thread
     const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
     *reinterpret_cast<f32x4*>(dst) = f32x4{patch_transform((s4.x - loc) * inv, d), patch_transform((s4.y - loc) * inv, d),
                                             patch_transform((s4.z - loc) * inv, d), patch_transform((s4.w - loc) * inv, d)};
-  } else {
-    for (int j = 0; j < p.P; ++j) {
-      const float z = (src[j * d.sw] - loc) * inv;
-      elem<T>::store(dst + j, patch_transform(z, d));
-    }
   }
   // zero the K padding of this row (done by the threads of the last variable's last piece)
   if (q == q_per_row - 1 && p.k_offset + q_per_row * p.P == p.K_total) {
     T* pad = reinterpret_cast<T*>(p.out) + row * p.Kpad;
     for (int64_t k = p.K_total; k < p.Kpad; ++k) elem<T>::store(pad + k, 0.f);
   }
+}
+
+// Any patch size (10 at 0.1 degree, 3 for the air-pollution model): one thread per PIXEL, consecutive threads on consecutive
+// longitudes of one image row -- every load instruction of a wave reads 256 contiguous bytes of the input field; the
+// stores land as runs of P values in the rows of neighbouring patches, which the L2 merges with the runs of the other
+// image rows / variables of the same patches (written by waves close in time).  (The form this replaces gave a thread one
+// P-value piece and looped over it: 64 lanes x 64 different cache lines per load, 1.1 TB/s on the 0.1-degree grid.)
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_pixels_kernel(const PatchArgs p) {
+  const int W = p.Wp * p.P;
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t lines = (int64_t)p.n_lvl * p.B * p.Hp * p.n_vars * p.T * p.P;   // (c, b, hp, v, t, i)
+  if (item >= lines * W) return;
+  const int x = (int)(item % W);
+  int64_t r = item / W;
+  const int i = (int)(r % p.P); r /= p.P;
+  const int t = (int)(r % p.T); r /= p.T;
+  const int v = (int)(r % p.n_vars); r /= p.n_vars;
+  const int hp = (int)(r % p.Hp); r /= p.Hp;
+  const int b = (int)(r % p.B);
+  const int c = (int)(r / p.B);
+  const int wp = x / p.P, j = x - wp * p.P;
+  const PatchVar& d = p.v[v];
+  const float z = (d.src[b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)x * d.sw] - d.loc[c]) * d.inv_scale[c];
+  const int64_t row = ((int64_t)c * p.B + b) * ((int64_t)p.Hp * p.Wp) + (int64_t)hp * p.Wp + wp;
+  T* out = reinterpret_cast<T*>(p.out) + row * p.Kpad;
+  const int vt = v * p.T + t;
+  elem<T>::store(out + p.k_offset + (int64_t)vt * p.P * p.P + i * p.P + j, patch_transform(z, d));
+  // zero the K padding of the patch's row (by the thread of its last value in the call that ends at K_total)
+  if (vt == p.n_vars * p.T - 1 && i == p.P - 1 && j == p.P - 1 && p.k_offset + p.n_vars * p.T * p.P * p.P == p.K_total)
+    for (int64_t k = p.K_total; k < p.Kpad; ++k) elem<T>::store(out + k, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -235,14 +262,21 @@ struct UnpatchArgs {
   int vec4;   // P == 4 and every source / destination piece is 16-byte aligned
 };
 
+// VEC = 4: patch size 4, aligned: a thread owns one patch row (16-byte pieces).  VEC = 1: any patch size: a thread owns one
+// PIXEL, consecutive threads on consecutive longitudes, so that every store of a wave writes 256 contiguous bytes of the
+// output field (the loads are runs of P head outputs per patch; the other image rows of the same patches read the rest of
+// those lines out of L2).
+template <int VEC>
 __global__ __launch_bounds__(256) void unpatchify_kernel(const UnpatchArgs p) {
-  // item = (v, b, c, hp, i, wp), wp fastest: neighbouring threads write one output row.
-  const int64_t per_var = (int64_t)p.B * p.n_lvl * p.Hp * p.P * p.Wp;
+  // item = (v, b, c, hp, i, wp [, j]), fastest last: neighbouring threads write one output row.
+  const int per_row = VEC == 4 ? p.Wp : p.Wp * p.P;
+  const int64_t per_var = (int64_t)p.B * p.n_lvl * p.Hp * p.P * per_row;
   const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (item >= per_var * p.n_vars) return;
   const int v = (int)(item / per_var);
   int64_t r = item - (int64_t)v * per_var;
-  const int wp = (int)(r % p.Wp); r /= p.Wp;
+  const int xx = (int)(r % per_row); r /= per_row;
+  const int wp = VEC == 4 ? xx : xx / p.P, j0 = VEC == 4 ? 0 : xx - wp * p.P;
   const int i = (int)(r % p.P); r /= p.P;
   const int hp = (int)(r % p.Hp); r /= p.Hp;
   const int c = (int)(r % p.n_lvl);
@@ -278,12 +312,12 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const UnpatchArgs p) {
     }
     return z * sc + loc;
   };
-  if (p.P == 4 && p.vec4) {   // patch size 4 (every model but the high-res / air-pollution ones): 16-byte pieces
+  if constexpr (VEC == 4) {   // patch size 4 (every model but the high-res / air-pollution ones): 16-byte pieces
     const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
     *reinterpret_cast<f32x4*>(dst) = f32x4{finish(s4.x, 0), finish(s4.y, 1), finish(s4.z, 2), finish(s4.w, 3)};
-    return;
+  } else {
+    dst[j0] = finish(src[j0], j0);
   }
-  for (int j = 0; j < p.P; ++j) dst[j] = finish(src[j], j);
 }
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
@@ -311,10 +345,22 @@ extern "C" int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, voi
   p.n_vars = n_vars; p.B = B; p.T = T; p.n_lvl = n_lvl; p.Hp = Hp; p.Wp = Wp; p.P = P;
   const int64_t items = (int64_t)n_lvl * B * Hp * Wp * n_vars * T * P;
   AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "patchify: bad problem size");
-  if (dtype == AURORA_F32)
-    hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
-  else
-    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+  bool vec4 = P == 4 && dtype == AURORA_F32 && (uintptr_t)out % 16 == 0 && Kpad % 4 == 0 && k_offset % 4 == 0;
+  for (int v = 0; v < n_vars && vec4; ++v) {
+    const aurora_patch_var& s = desc[v];
+    vec4 = s.stride_w == 1 && (uintptr_t)s.src % 16 == 0 && s.stride_b % 4 == 0 && s.stride_t % 4 == 0 && s.stride_c % 4 == 0 &&
+           s.stride_h % 4 == 0;
+  }
+  if (vec4) {
+    hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+  } else {
+    const int64_t pixels = items * P;
+    AURORA_CHECK_ARG((pixels + 255) / 256 < ((int64_t)1 << 31), "patchify: bad problem size");
+    if (dtype == AURORA_F32)
+      hipLaunchKernelGGL(patchify_pixels_kernel<float>, dim3(blocks_for(pixels, 256)), dim3(256), 0, as_stream(stream), p);
+    else
+      hipLaunchKernelGGL(patchify_pixels_kernel<bf16_t>, dim3(blocks_for(pixels, 256)), dim3(256), 0, as_stream(stream), p);
+  }
   return check_launch("patchify");
 }
 
@@ -388,8 +434,15 @@ extern "C" int aurora_hip_unpatchify(const float* y, int64_t ldy, const aurora_u
   for (int v = 0; v < n_vars && al; ++v)
     al = (uintptr_t)desc[v].dst % 16 == 0 && desc[v].col0 % 4 == 0 && desc[v].lvl_stride % 4 == 0;
   p.vec4 = al ? 1 : 0;
-  const int64_t items = (int64_t)n_vars * B * n_lvl * Hp * P * Wp;
+  for (int v = 0; v < n_vars && al; ++v)   // (the optional head columns and planes of the post-decoder hooks as well)
+    al = (desc[v].mod_col0 < 0 || (desc[v].mod_col0 % 4 == 0 && (uintptr_t)desc[v].prev % 16 == 0 && desc[v].prev_sb % 4 == 0 &&
+                                   desc[v].prev_sc % 4 == 0 && desc[v].prev_sh % 4 == 0)) &&
+         (desc[v].angle_col0 < 0 || desc[v].angle_col0 % 4 == 0) &&
+         (desc[v].dens_col0 < 0 || (desc[v].dens_col0 % 4 == 0 && (uintptr_t)desc[v].mask % 16 == 0 && desc[v].mask_sh % 4 == 0));
+  p.vec4 = al ? 1 : 0;
+  const int64_t items = (int64_t)n_vars * B * n_lvl * Hp * P * Wp * (al ? 1 : P);
   AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "unpatchify: bad problem size");
-  hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+  if (al) hipLaunchKernelGGL(unpatchify_kernel<4>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+  else hipLaunchKernelGGL(unpatchify_kernel<1>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
   return check_launch("unpatchify");
 }
