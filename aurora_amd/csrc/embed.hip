@@ -82,35 +82,40 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
   }
 }
 
-// Any patch size (10 at 0.1 degree, 3 for the air-pollution model): one thread per PIXEL, consecutive threads on consecutive
-// longitudes of one image row -- every load instruction of a wave reads 256 contiguous bytes of the input field; the
-// stores land as runs of P values in the rows of neighbouring patches, which the L2 merges with the runs of the other
-// image rows / variables of the same patches (written by waves close in time).  (The form this replaces gave a thread one
-// P-value piece and looped over it: 64 lanes x 64 different cache lines per load, 1.1 TB/s on the 0.1-degree grid.)
+// Any patch size (10 at 0.1 degree, 3 for the air-pollution model): one thread per OUTPUT element, consecutive threads on
+// consecutive columns k = (v, t, i, j) of one patch's row of the GEMM operand -- every store instruction of a wave writes
+// 256 contiguous bytes; the loads are runs of P pixels per image row (the neighbouring patches, handled by the next rows'
+// threads, use the rest of those cache lines out of L1 / L2).  The first form gave a thread one P-value piece and looped
+// over it (one 4-byte load per lane and instruction, 64 cache lines each: 1.1 TB/s on the 0.1-degree grid); a
+// pixel-per-thread form with coalesced loads and scattered 40-byte stores was no faster: partial-line WRITES are what hurts.
 template <typename T>
-__global__ __launch_bounds__(256) void patchify_pixels_kernel(const PatchArgs p) {
-  const int W = p.Wp * p.P;
+__global__ __launch_bounds__(256) void patchify_cols_kernel(const PatchArgs p, const int k_end) {
+  // k runs over this call's columns [k_offset, k_end): its variables, plus the zero padding if the call ends at K_total
+  const int n_k = k_end - p.k_offset;
   const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t lines = (int64_t)p.n_lvl * p.B * p.Hp * p.n_vars * p.T * p.P;   // (c, b, hp, v, t, i)
-  if (item >= lines * W) return;
-  const int x = (int)(item % W);
-  int64_t r = item / W;
-  const int i = (int)(r % p.P); r /= p.P;
-  const int t = (int)(r % p.T); r /= p.T;
-  const int v = (int)(r % p.n_vars); r /= p.n_vars;
-  const int hp = (int)(r % p.Hp); r /= p.Hp;
-  const int b = (int)(r % p.B);
-  const int c = (int)(r / p.B);
-  const int wp = x / p.P, j = x - wp * p.P;
+  const int64_t rows = (int64_t)p.n_lvl * p.B * p.Hp * p.Wp;
+  if (item >= rows * n_k) return;
+  const int64_t row = item / n_k;
+  const int kk = (int)(item - row * n_k);
+  T* dst = reinterpret_cast<T*>(p.out) + row * p.Kpad + p.k_offset + kk;
+  const int PP = p.P * p.P;
+  const int vt = kk / PP;
+  if (vt >= p.n_vars * p.T) {   // K padding
+    elem<T>::store(dst, 0.f);
+    return;
+  }
+  const int ij = kk - vt * PP;
+  const int i = ij / p.P, j = ij - i * p.P;
+  const int t = vt % p.T, v = vt / p.T;
+  const int64_t L = (int64_t)p.Hp * p.Wp;
+  const int l = (int)(row % L);
+  const int64_t cb = row / L;  // rows are (level, batch, patch)
+  const int b = (int)(cb % p.B), c = (int)(cb / p.B);
+  const int hp = l / p.Wp, wp = l - hp * p.Wp;
   const PatchVar& d = p.v[v];
-  const float z = (d.src[b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)x * d.sw] - d.loc[c]) * d.inv_scale[c];
-  const int64_t row = ((int64_t)c * p.B + b) * ((int64_t)p.Hp * p.Wp) + (int64_t)hp * p.Wp + wp;
-  T* out = reinterpret_cast<T*>(p.out) + row * p.Kpad;
-  const int vt = v * p.T + t;
-  elem<T>::store(out + p.k_offset + (int64_t)vt * p.P * p.P + i * p.P + j, patch_transform(z, d));
-  // zero the K padding of the patch's row (by the thread of its last value in the call that ends at K_total)
-  if (vt == p.n_vars * p.T - 1 && i == p.P - 1 && j == p.P - 1 && p.k_offset + p.n_vars * p.T * p.P * p.P == p.K_total)
-    for (int64_t k = p.K_total; k < p.Kpad; ++k) elem<T>::store(out + k, 0.f);
+  const float z = (d.src[b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)(wp * p.P + j) * d.sw] - d.loc[c]) *
+                  d.inv_scale[c];
+  elem<T>::store(dst, patch_transform(z, d));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -354,12 +359,13 @@ extern "C" int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, voi
   if (vec4) {
     hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
   } else {
-    const int64_t pixels = items * P;
-    AURORA_CHECK_ARG((pixels + 255) / 256 < ((int64_t)1 << 31), "patchify: bad problem size");
+    const int k_end = k_offset + n_vars * T * P * P == K_total ? (int)Kpad : k_offset + n_vars * T * P * P;
+    const int64_t elems = (int64_t)n_lvl * B * Hp * Wp * (k_end - k_offset);
+    AURORA_CHECK_ARG((elems + 255) / 256 < ((int64_t)1 << 31), "patchify: bad problem size");
     if (dtype == AURORA_F32)
-      hipLaunchKernelGGL(patchify_pixels_kernel<float>, dim3(blocks_for(pixels, 256)), dim3(256), 0, as_stream(stream), p);
+      hipLaunchKernelGGL(patchify_cols_kernel<float>, dim3(blocks_for(elems, 256)), dim3(256), 0, as_stream(stream), p, k_end);
     else
-      hipLaunchKernelGGL(patchify_pixels_kernel<bf16_t>, dim3(blocks_for(pixels, 256)), dim3(256), 0, as_stream(stream), p);
+      hipLaunchKernelGGL(patchify_cols_kernel<bf16_t>, dim3(blocks_for(elems, 256)), dim3(256), 0, as_stream(stream), p, k_end);
   }
   return check_launch("patchify");
 }
