@@ -89,29 +89,27 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
 // over it (one 4-byte load per lane and instruction, 64 cache lines each: 1.1 TB/s on the 0.1-degree grid); a
 // pixel-per-thread form with coalesced loads and scattered 40-byte stores was no faster: partial-line WRITES are what hurts.
 template <typename T>
-__global__ __launch_bounds__(256) void patchify_cols_kernel(const PatchArgs p, const int k_end) {
-  // k runs over this call's columns [k_offset, k_end): its variables, plus the zero padding if the call ends at K_total
+__global__ __launch_bounds__(256) void patchify_cols_kernel(const PatchArgs p, const int k_end, const int chunks) {
+  // grid: x = (patch column, 256-column chunk of the row), y = patch row, z = (level, batch) -- 32-bit index arithmetic
+  // only (a flat 64-bit item index cost six 64-bit divisions per element: the kernel was bound by them, not by memory).
+  // k runs over this call's columns [k_offset, k_end): its variables, plus the zero padding if the call ends at K_total.
   const int n_k = k_end - p.k_offset;
-  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t rows = (int64_t)p.n_lvl * p.B * p.Hp * p.Wp;
-  if (item >= rows * n_k) return;
-  const int64_t row = item / n_k;
-  const int kk = (int)(item - row * n_k);
+  const unsigned wp = blockIdx.x / (unsigned)chunks, chunk = blockIdx.x - wp * (unsigned)chunks;
+  const int kk = (int)(chunk * 256u + threadIdx.x);
+  if (kk >= n_k) return;
+  const unsigned hp = blockIdx.y;
+  const unsigned c = blockIdx.z / (unsigned)p.B, b = blockIdx.z - c * (unsigned)p.B;
+  const int64_t row = ((int64_t)blockIdx.z * p.Hp + hp) * p.Wp + wp;   // rows are (level, batch, patch)
   T* dst = reinterpret_cast<T*>(p.out) + row * p.Kpad + p.k_offset + kk;
-  const int PP = p.P * p.P;
-  const int vt = kk / PP;
-  if (vt >= p.n_vars * p.T) {   // K padding
+  const unsigned PP = (unsigned)(p.P * p.P);
+  const unsigned vt = (unsigned)kk / PP;
+  if ((int)vt >= p.n_vars * p.T) {   // K padding
     elem<T>::store(dst, 0.f);
     return;
   }
-  const int ij = kk - vt * PP;
-  const int i = ij / p.P, j = ij - i * p.P;
-  const int t = vt % p.T, v = vt / p.T;
-  const int64_t L = (int64_t)p.Hp * p.Wp;
-  const int l = (int)(row % L);
-  const int64_t cb = row / L;  // rows are (level, batch, patch)
-  const int b = (int)(cb % p.B), c = (int)(cb / p.B);
-  const int hp = l / p.Wp, wp = l - hp * p.Wp;
+  const unsigned ij = (unsigned)kk - vt * PP;
+  const unsigned i = ij / (unsigned)p.P, j = ij - i * (unsigned)p.P;
+  const unsigned v = vt / (unsigned)p.T, t = vt - v * (unsigned)p.T;
   const PatchVar& d = p.v[v];
   const float z = (d.src[b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)(wp * p.P + j) * d.sw] - d.loc[c]) *
                   d.inv_scale[c];
@@ -273,19 +271,30 @@ struct UnpatchArgs {
 // those lines out of L2).
 template <int VEC>
 __global__ __launch_bounds__(256) void unpatchify_kernel(const UnpatchArgs p) {
-  // item = (v, b, c, hp, i, wp [, j]), fastest last: neighbouring threads write one output row.
-  const int per_row = VEC == 4 ? p.Wp : p.Wp * p.P;
-  const int64_t per_var = (int64_t)p.B * p.n_lvl * p.Hp * p.P * per_row;
-  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= per_var * p.n_vars) return;
-  const int v = (int)(item / per_var);
-  int64_t r = item - (int64_t)v * per_var;
-  const int xx = (int)(r % per_row); r /= per_row;
-  const int wp = VEC == 4 ? xx : xx / p.P, j0 = VEC == 4 ? 0 : xx - wp * p.P;
-  const int i = (int)(r % p.P); r /= p.P;
-  const int hp = (int)(r % p.Hp); r /= p.Hp;
-  const int c = (int)(r % p.n_lvl);
-  const int b = (int)(r / p.n_lvl);
+  int v, wp, j0, i, hp, c, b;
+  if constexpr (VEC == 4) {
+    // item = (v, b, c, hp, i, wp), wp fastest: neighbouring threads write one output row.
+    const int64_t per_var = (int64_t)p.B * p.n_lvl * p.Hp * p.P * p.Wp;
+    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= per_var * p.n_vars) return;
+    v = (int)(item / per_var);
+    int64_t r = item - (int64_t)v * per_var;
+    wp = (int)(r % p.Wp); r /= p.Wp;
+    j0 = 0;
+    i = (int)(r % p.P); r /= p.P;
+    hp = (int)(r % p.Hp); r /= p.Hp;
+    c = (int)(r % p.n_lvl);
+    b = (int)(r / p.n_lvl);
+  } else {
+    // grid: x = 256-pixel chunk of an image row, y = image row, z = (variable, batch, level): 32-bit index arithmetic only
+    const unsigned x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= (unsigned)(p.Wp * p.P)) return;
+    wp = (int)(x / (unsigned)p.P); j0 = (int)(x - (unsigned)wp * (unsigned)p.P);
+    hp = (int)(blockIdx.y / (unsigned)p.P); i = (int)(blockIdx.y - (unsigned)hp * (unsigned)p.P);
+    const unsigned vb = blockIdx.z / (unsigned)p.n_lvl;
+    c = (int)(blockIdx.z - vb * (unsigned)p.n_lvl);
+    v = (int)(vb / (unsigned)p.B); b = (int)(vb - (unsigned)v * (unsigned)p.B);
+  }
   const UnpatchVar& d = p.v[v];
   const int64_t L = (int64_t)p.Hp * p.Wp;
   const float* row = p.y + (((int64_t)b * L + (int64_t)hp * p.Wp + wp) * p.n_lvl + c) * p.ldy + c * d.lvl_stride + i * p.P;
@@ -360,12 +369,14 @@ extern "C" int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, voi
     hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
   } else {
     const int k_end = k_offset + n_vars * T * P * P == K_total ? (int)Kpad : k_offset + n_vars * T * P * P;
-    const int64_t elems = (int64_t)n_lvl * B * Hp * Wp * (k_end - k_offset);
-    AURORA_CHECK_ARG((elems + 255) / 256 < ((int64_t)1 << 31), "patchify: bad problem size");
+    const int chunks = (k_end - k_offset + 255) / 256;
+    AURORA_CHECK_ARG((int64_t)Wp * chunks < ((int64_t)1 << 31) && Hp <= 65535 && (int64_t)n_lvl * B <= 65535,
+                     "patchify: grid too large (%d x %d patches, %d levels x %d)", Hp, Wp, n_lvl, B);
+    const dim3 grid((unsigned)(Wp * chunks), (unsigned)Hp, (unsigned)(n_lvl * B));
     if (dtype == AURORA_F32)
-      hipLaunchKernelGGL(patchify_cols_kernel<float>, dim3(blocks_for(elems, 256)), dim3(256), 0, as_stream(stream), p, k_end);
+      hipLaunchKernelGGL(patchify_cols_kernel<float>, grid, dim3(256), 0, as_stream(stream), p, k_end, chunks);
     else
-      hipLaunchKernelGGL(patchify_cols_kernel<bf16_t>, dim3(blocks_for(elems, 256)), dim3(256), 0, as_stream(stream), p, k_end);
+      hipLaunchKernelGGL(patchify_cols_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), p, k_end, chunks);
   }
   return check_launch("patchify");
 }
@@ -446,9 +457,14 @@ extern "C" int aurora_hip_unpatchify(const float* y, int64_t ldy, const aurora_u
          (desc[v].angle_col0 < 0 || desc[v].angle_col0 % 4 == 0) &&
          (desc[v].dens_col0 < 0 || (desc[v].dens_col0 % 4 == 0 && (uintptr_t)desc[v].mask % 16 == 0 && desc[v].mask_sh % 4 == 0));
   p.vec4 = al ? 1 : 0;
-  const int64_t items = (int64_t)n_vars * B * n_lvl * Hp * P * Wp * (al ? 1 : P);
+  const int64_t items = (int64_t)n_vars * B * n_lvl * Hp * P * Wp;
   AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "unpatchify: bad problem size");
-  if (al) hipLaunchKernelGGL(unpatchify_kernel<4>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
-  else hipLaunchKernelGGL(unpatchify_kernel<1>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+  if (al) {
+    hipLaunchKernelGGL(unpatchify_kernel<4>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+  } else {
+    AURORA_CHECK_ARG((int64_t)Hp * P <= 65535 && (int64_t)n_vars * B * n_lvl <= 65535, "unpatchify: grid too large");
+    const dim3 grid((unsigned)((Wp * P + 255) / 256), (unsigned)(Hp * P), (unsigned)(n_vars * B * n_lvl));
+    hipLaunchKernelGGL(unpatchify_kernel<1>, grid, dim3(256), 0, as_stream(stream), p);
+  }
   return check_launch("unpatchify");
 }
