@@ -1,8 +1,7 @@
 """aurora_amd: an MI355X-native forward / rollout engine for the Aurora model family.
 
-Public surface = the reference's (aurora/__init__.py:3-29).  `Tracker` is exported as a stub: the cyclone tracker
-(aurora/tracker.py) is CPU post-processing of finished predictions, outside the forward / roll-out hot path this
-package accelerates.
+Public surface = the reference's (aurora/__init__.py:3-29).  The cyclone tracker (aurora/tracker.py) follows a roll-out
+without moving the predictions off the device: only its search windows travel (aurora_amd/tracker.py).
 """
 
 from aurora_amd.batch import Batch, Metadata
@@ -17,20 +16,7 @@ from aurora_amd.model.aurora import (
     AuroraWave,
 )
 from aurora_amd.rollout import rollout, write_rollout
-
-
-class Tracker:
-    """Placeholder for the reference's tropical-cyclone tracker (aurora/tracker.py).
-
-    The tracker consumes finished predictions on the CPU (scipy / numpy peak finding); nothing of it is on the
-    forward / roll-out path.  `Batch` objects produced by aurora_amd have exactly the reference's fields, so the
-    reference's own `Tracker` can be fed with them: `aurora.Tracker(...).step(pred.to("cpu"))`."""
-
-    def __init__(self, *args, **kwargs) -> None:
-        raise NotImplementedError(
-            "aurora_amd accelerates Aurora.forward / rollout only; use the reference's `aurora.Tracker` on the "
-            "predictions (they are field-compatible `Batch` objects)."
-        )
+from aurora_amd.tracker import Tracker
 
 __all__ = [
     "Aurora",
