@@ -8,6 +8,7 @@ mean|out - ref| / mean|ref| per variable, plus a max-norm guard):
         CPU autocast path (the oracle with autocast=True) deviates from fp32.
 """
 import dataclasses
+from datetime import timedelta
 
 import numpy as np
 import pytest
@@ -121,6 +122,47 @@ def test_readme_example_runs_unchanged():
         assert helpers.mean_rel_err(v.cpu(), o_s[k]) < 1e-4
     for k, v in pred.atmos_vars.items():
         assert helpers.mean_rel_err(v.cpu(), o_a[k]) < 1e-4
+
+
+def test_lat_lon_matrices_give_the_vector_result():
+    """tests/test_model.py:126-160 upstream: latitude / longitude matrices instead of vectors, same prediction (rtol 1e-5)."""
+    case, model, batch = build("small_b2")
+    with torch.inference_mode():
+        pred = model.forward(batch)
+        n_lat, n_lon = len(batch.metadata.lat), len(batch.metadata.lon)
+        meta = dataclasses.replace(batch.metadata, lat=batch.metadata.lat[:, None].expand(n_lat, n_lon),
+                                   lon=batch.metadata.lon[None, :].expand(n_lat, n_lon))
+        pred_matrix = model.forward(dataclasses.replace(batch, metadata=meta))
+    for a, b in ((pred.surf_vars, pred_matrix.surf_vars), (pred.static_vars, pred_matrix.static_vars),
+                 (pred.atmos_vars, pred_matrix.atmos_vars)):
+        for k in a:
+            np.testing.assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), rtol=1e-5)
+    assert pred_matrix.metadata.lat.dim() == 2   # the prediction carries the caller's (cropped) matrices on
+
+
+def test_flags_change_the_prediction():
+    """tests/test_model.py:163-200 upstream: `stabilise_level_agg` and a 12 h `timestep` each give a different model (surface
+    and atmospheric predictions differ beyond rtol 5e-2 somewhere), static variables pass through unchanged."""
+    case = CASES["small_b2"]
+    preds = []
+    for flags in ({}, {"stabilise_level_agg": True}, {"timestep": timedelta(hours=12)}):
+        model = aurora_amd.AuroraSmallPretrained(**case["kwargs"], use_lora=True, **flags)
+        sd = helpers.case_state_dict(model, torch.float32)
+        model.load_state_dict(sd, strict=True)
+        model = model.to("cuda").eval()
+        surf, static, atmos, lat, lon, times = helpers.case_inputs(case, model.config)
+        f = lambda d: {k: v.float() for k, v in d.items()}  # noqa: E731
+        batch = Batch(f(surf), f(static), f(atmos), Metadata(lat.float(), lon.float(), times, tuple(case["levels"])))
+        with torch.inference_mode():
+            preds.append(model.forward(batch).normalise(model.surf_stats).to("cpu"))
+    for i, p1 in enumerate(preds):
+        for p2 in preds[i + 1:]:
+            for k in p1.surf_vars:
+                assert not np.allclose(p1.surf_vars[k], p2.surf_vars[k], rtol=5e-2), k
+            for k in p1.static_vars:
+                np.testing.assert_allclose(p1.static_vars[k], p2.static_vars[k], rtol=1e-5)
+            for k in p1.atmos_vars:
+                assert not np.allclose(p1.atmos_vars[k], p2.atmos_vars[k], rtol=5e-2), k
 
 
 def test_lora_single_vs_all_equal_at_step0_only():
