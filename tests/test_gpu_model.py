@@ -124,6 +124,28 @@ def test_readme_example_runs_unchanged():
         assert helpers.mean_rel_err(v.cpu(), o_a[k]) < 1e-4
 
 
+def test_model_runs_wrapped_in_ddp():
+    """tests/test_model.py:96-110 upstream (the reference's only collective): the model inside DistributedDataParallel,
+    gloo, world size one -- "just test that it runs", and that it predicts what the bare model predicts."""
+    import torch.distributed as dist
+
+    case, model, batch = build("small_b2")
+    with torch.inference_mode():
+        want = model.forward(batch)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1, store=dist.HashStore())
+    try:
+        wrapped = torch.nn.parallel.DistributedDataParallel(model)
+        with torch.inference_mode():
+            got = wrapped.forward(batch)
+        for k, v in want.surf_vars.items():
+            assert torch.equal(got.surf_vars[k], v)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_lat_lon_matrices_give_the_vector_result():
     """tests/test_model.py:126-160 upstream: latitude / longitude matrices instead of vectors, same prediction (rtol 1e-5)."""
     case, model, batch = build("small_b2")
