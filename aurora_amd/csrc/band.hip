@@ -71,36 +71,126 @@ std::vector<Res> stage_resolutions(Res res0, int n_stages) {
   return out;
 }
 
-bool band_rows(const std::vector<Res>& all_res, const int window[3], int world,
-               std::vector<std::vector<std::array<int, 2>>>& rows) {
-  const int n = (int)all_res.size();
-  const int Hc = all_res.back().h;
-  // boundaries fall on window rows of the finer stages when possible (then un-shifted blocks need no halo there)
-  int unit = n > 1 ? window[1] / std::gcd(window[1], 2) : window[1];
-  if (unit < 1 || (Hc + unit - 1) / unit < world) unit = 1;
-  const int n_units = (Hc + unit - 1) / unit;
-  if (n_units < world) {
-    set_error("cannot split %d latitude rows of the coarsest stage over %d ranks", Hc, world);
-    return false;
-  }
-  const int base = n_units / world, extra = n_units % world;
-  std::vector<int> bounds{0};
-  for (int r = 0; r < world; ++r) bounds.push_back(bounds.back() + (base + (r < extra ? 1 : 0)) * unit);
-  for (int& b : bounds) b = std::min(b, Hc);
-  bounds.back() = Hc;
+namespace {
+
+// Owned rows of every rank at every stage from boundaries on the coarsest stage (doubled per finer stage, clipped to the
+// stage's rows); false if a rank ends up without rows somewhere.
+bool rows_from_bounds(const std::vector<Res>& all_res, const std::vector<int>& bounds,
+                      std::vector<std::vector<std::array<int, 2>>>& rows, int* bad_rank, int* bad_stage) {
+  const int n = (int)all_res.size(), world = (int)bounds.size() - 1;
   rows.assign(n, {});
   for (int s = 0; s < n; ++s) {
     const int mult = 1 << (n - 1 - s), Hs = all_res[s].h;
     for (int r = 0; r < world; ++r) {
       const int h0 = std::min(bounds[r] * mult, Hs), h1 = r < world - 1 ? std::min(bounds[r + 1] * mult, Hs) : Hs;
       if (h1 <= h0) {
-        set_error("latitude-band partition: rank %d of %d ends up without rows at stage %d (%d rows)", r, world, s, Hs);
+        if (bad_rank) *bad_rank = r;
+        if (bad_stage) *bad_stage = s;
         return false;
       }
       rows[s].push_back({h0, h1});
     }
   }
   return true;
+}
+
+// Can every rank get what its windows need from its two neighbours?  Tokens that attend to each other -- a window's
+// positions of one mask group (band_plan below drops the rest) -- must lie on at most two adjacent ranks, in both block
+// flavours at every stage.  Only the latitude structure matters: checked on a grid one window wide.
+bool neighbours_suffice(const std::vector<Res>& all_res, const int window[3],
+                        const std::vector<std::vector<std::array<int, 2>>>& rows) {
+  for (size_t s = 0; s < all_res.size(); ++s) {
+    const Res res{all_res[s].c, all_res[s].h, std::min(all_res[s].w, window[2])};
+    std::vector<int> owner(res.h, -1);
+    for (size_t r = 0; r < rows[s].size(); ++r)
+      for (int h = rows[s][r][0]; h < rows[s][r][1]; ++h) owner[h] = (int)r;
+    for (int shifted = 0; shifted < 2; ++shifted) {
+      const WindowTables t = window_tables(res, window, shifted != 0);
+      for (int w = 0; w < t.n_windows; ++w) {
+        int lo[28], hi[28];
+        for (int g = 0; g < 28; ++g) { lo[g] = 1 << 30; hi[g] = -1; }
+        for (int i = 0; i < t.n_tok; ++i) {
+          const int32_t tk = t.tok[(size_t)w * t.n_tok + i];
+          if (tk < 0) continue;
+          const int g = t.grp.empty() ? 0 : t.grp[(size_t)w * t.n_tok + i], o = owner[(tk / res.w) % res.h];
+          lo[g] = std::min(lo[g], o);
+          hi[g] = std::max(hi[g], o);
+        }
+        for (int g = 0; g < 28; ++g)
+          if (hi[g] - lo[g] > 1) return false;
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+bool band_rows(const std::vector<Res>& all_res, const int window[3], int world,
+               std::vector<std::vector<std::array<int, 2>>>& rows) {
+  const int n = (int)all_res.size();
+  const int Hc = all_res.back().h;
+  if (Hc < world) {
+    set_error("cannot split %d latitude rows of the coarsest stage over %d ranks", Hc, world);
+    return false;
+  }
+  // First choice: boundaries on window rows of the finer stages (then un-shifted blocks need no halo there).
+  int unit = n > 1 ? window[1] / std::gcd(window[1], 2) : window[1];
+  if (unit < 1 || (Hc + unit - 1) / unit < world) unit = 1;
+  const int n_units = (Hc + unit - 1) / unit;
+  const int base = n_units / world, extra = n_units % world;
+  std::vector<int> bounds{0};
+  for (int r = 0; r < world; ++r) bounds.push_back(bounds.back() + (base + (r < extra ? 1 : 0)) * unit);
+  for (int& b : bounds) b = std::min(b, Hc);
+  bounds.back() = Hc;
+  int bad_rank = 0, bad_stage = 0;
+  const bool has_rows = rows_from_bounds(all_res, bounds, rows, &bad_rank, &bad_stage);
+  // ... kept unless it is badly balanced: its largest band more than 1/12 above the smallest possible largest band
+  // (38 rows over 4 ranks: 12 + 9 + 9 + 8 against 10 + 10 + 9 + 9 -- the slowest rank bounds the step)
+  const int m_opt = (Hc + world - 1) / world;
+  int m_unit = 0;
+  for (int r = 0; r < world; ++r) m_unit = std::max(m_unit, bounds[r + 1] - bounds[r]);
+  if (has_rows && (m_unit - m_opt) * 12 <= m_opt && neighbours_suffice(all_res, window, rows)) return true;
+  // Otherwise -- and for thin bands (many ranks for the grid: the 0.4-degree grid on 8), where a window of the aligned split
+  // may reach past a whole band -- search the partitions with the smallest largest band, thick bands first, for one whose
+  // windows stay within neighbouring ranks.
+  std::vector<int> sizes(world, 0);
+  long budget = 2000000;
+  for (int m = (Hc + world - 1) / world; m <= Hc; ++m) {
+    // iterative depth-first search over band sizes 1 .. m that sum to Hc
+    int r = 0, remaining = Hc;
+    sizes[0] = std::min(m, remaining - (world - 1)) + 1;   // "one above the first candidate"
+    while (r >= 0) {
+      const int left = world - 1 - r;                      // bands still to size after this one
+      int sz = sizes[r] - 1;                               // next candidate for band r
+      const int least = std::max(1, remaining - left * m); // smaller would leave too much for the rest
+      if (sz < least) {                                    // exhausted: back up
+        if (--r >= 0) remaining += sizes[r];
+        continue;
+      }
+      sizes[r] = sz;
+      if (left == 0) {                                     // (then sz == remaining by the bounds above, or no fit)
+        if (sz == remaining && --budget >= 0) {
+          std::vector<int> b{0};
+          for (int q = 0; q < world; ++q) b.push_back(b.back() + sizes[q]);
+          if (rows_from_bounds(all_res, b, rows, nullptr, nullptr) && neighbours_suffice(all_res, window, rows)) return true;
+        }
+        sizes[r] = least;                                  // no other size fits the last band
+        continue;
+      }
+      remaining -= sz;
+      ++r;
+      sizes[r] = std::min(m, remaining - (world - 1 - r)) + 1;
+    }
+    if (budget < 0) break;
+  }
+  if (!has_rows)
+    set_error("latitude-band partition: rank %d of %d ends up without rows at stage %d (%d rows)", bad_rank, world, bad_stage,
+              all_res[bad_stage].h);
+  else
+    set_error("latitude-band partition: no split of %d coarsest-stage rows over %d ranks keeps every window within two "
+              "neighbouring ranks (bands too thin)", Hc, world);
+  return false;
 }
 
 bool band_plan(Res res, const int window[3], bool shifted, int rank, const std::vector<std::array<int, 2>>& rows,

@@ -37,36 +37,86 @@ from aurora_amd.engine import geometry
 Res = tuple[int, int, int]
 
 
+def _rows_from_bounds(all_res: list[Res], bounds: list[int]) -> list[list[tuple[int, int]]] | None:
+    """Owned rows `[stage][rank]` from boundaries on the coarsest stage; None if a rank ends up without rows."""
+    n, world = len(all_res), len(bounds) - 1
+    out = []
+    for s in range(n):
+        mult, Hs = 2 ** (n - 1 - s), all_res[s][1]
+        rows = [(min(bounds[r] * mult, Hs), min(bounds[r + 1] * mult, Hs) if r < world - 1 else Hs) for r in range(world)]
+        if any(h1 <= h0 for h0, h1 in rows):
+            return None
+        out.append(rows)
+    return out
+
+
+def _neighbours_suffice(all_res: list[Res], window: Res, rows: list[list[tuple[int, int]]]) -> bool:
+    """Tokens that attend to each other -- a window's positions of one mask group -- lie on at most two adjacent ranks, in
+    both block flavours at every stage (only the latitude structure matters: checked on a grid one window wide)."""
+    for s, (C, H, W) in enumerate(all_res):
+        res = (C, H, min(W, window[2]))
+        owner = np.full(H, -1)
+        for r, (h0, h1) in enumerate(rows[s]):
+            owner[h0:h1] = r
+        for shifted in (False, True):
+            tok, grp, _ = geometry.window_tables(res, window, shifted)
+            own = np.where(tok >= 0, owner[(np.maximum(tok, 0) // res[2]) % H], -1)
+            g = grp if grp is not None else np.zeros_like(tok, dtype=np.uint8)
+            for label in np.unique(g):
+                sel = (g == label) & (tok >= 0)
+                hi = np.where(sel, own, -1).max(axis=1)
+                lo = np.where(sel, own, 1 << 30).min(axis=1)
+                if np.any((hi - lo > 1) & sel.any(axis=1)):
+                    return False
+    return True
+
+
+def _compositions(world: int, total: int, m: int):
+    """`world` band sizes in 1 .. m summing to `total`, thick bands first (the order csrc/band.hip searches in)."""
+    if world == 1:
+        if 1 <= total <= m:
+            yield [total]
+        return
+    for sz in range(min(m, total - (world - 1)), max(1, total - (world - 1) * m) - 1, -1):
+        for rest in _compositions(world - 1, total - sz, m):
+            yield [sz] + rest
+
+
 def band_rows(all_res: list[Res], window: Res, world: int) -> list[list[tuple[int, int]]]:
     """Owned latitude rows `[stage][rank] -> (h0, h1)`.
 
     Boundaries are chosen on the coarsest stage and doubled per finer stage, so 2x2 merges / splits
-    never cross a rank.  When possible the unit is chosen such that the finer stages' boundaries fall
-    on window rows (then un-shifted blocks need no halo there).
+    never cross a rank.  First choice: a unit such that the finer stages' boundaries fall on window rows
+    (then un-shifted blocks need no halo there).  When that split is badly balanced, or bands get so thin that a
+    window would reach past a whole band (halo rows from a rank that is not a neighbour), the partitions with the
+    smallest largest band are searched, thick bands first, for one whose windows stay within neighbouring ranks.
     """
     n = len(all_res)
     Hc = all_res[-1][1]
+    if Hc < world:
+        raise ValueError(f"cannot split {Hc} latitude rows of the coarsest stage over {world} ranks")
     unit = window[1] // math.gcd(window[1], 2) if n > 1 else window[1]
     if unit < 1 or -(-Hc // unit) < world:
         unit = 1
     n_units = -(-Hc // unit)
-    if n_units < world:
-        raise ValueError(f"cannot split {Hc} latitude rows of the coarsest stage over {world} ranks")
     base, extra = divmod(n_units, world)
     bounds = [0]
     for r in range(world):
         bounds.append(bounds[-1] + (base + (1 if r < extra else 0)) * unit)
     bounds = [min(b, Hc) for b in bounds]
     bounds[-1] = Hc
-    out = []
-    for s in range(n):
-        mult = 2 ** (n - 1 - s)
-        Hs = all_res[s][1]
-        out.append([(min(bounds[r] * mult, Hs), min(bounds[r + 1] * mult, Hs) if r < world - 1 else Hs)
-                    for r in range(world)])
-    for rows in out:
-        assert all(h1 > h0 for h0, h1 in rows), "a rank ended up without rows"
-    return out
+    rows = _rows_from_bounds(all_res, bounds)
+    m_opt, m_unit = -(-Hc // world), max(b1 - b0 for b0, b1 in zip(bounds, bounds[1:]))
+    # kept unless badly balanced (largest band more than 1/12 above the smallest possible largest band)
+    if rows is not None and (m_unit - m_opt) * 12 <= m_opt and _neighbours_suffice(all_res, window, rows):
+        return rows
+    for m in range(-(-Hc // world), Hc + 1):
+        for sizes in _compositions(world, Hc, m):
+            rows = _rows_from_bounds(all_res, [0] + [int(x) for x in np.cumsum(sizes)])
+            if rows is not None and _neighbours_suffice(all_res, window, rows):
+                return rows
+    raise ValueError(f"no split of {Hc} coarsest-stage rows over {world} ranks keeps every window within two neighbouring "
+                     "ranks (bands too thin)")
 
 
 @dataclasses.dataclass

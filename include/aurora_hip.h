@@ -437,7 +437,9 @@ int aurora_hip_set_time_ex(aurora_hip_model* model, const double* time_hours, co
 /* ---- one forecast across several devices: latitude bands + halo exchange (the reference is
  * single-device) ---------------------------------------------------------------------------------------------------------
  * Every rank owns a contiguous band of latitude rows at every backbone stage (boundaries on the coarsest stage, doubled
- * per finer stage, so patch merges / splits stay local).  Everything except window attention is local to a token, a 2 x 2
+ * per finer stage, so patch merges / splits stay local; on window rows of the finer stages when that is balanced, else the
+ * most balanced split whose windows stay within two neighbouring ranks -- a rank exchanges with rank - 1 and rank + 1 only,
+ * aurora_hip_precompute fails if no such split exists).  Everything except window attention is local to a token, a 2 x 2
  * block or a grid column.  A shifted-window block needs k | v of the neighbouring band's first / last rows: the handle
  * gathers those rows of the block's INPUT into `send` staging buffers (half the bytes of k | v, and available before the
  * qkv GEMM), calls `post` (start sending / receiving; asynchronous to `stream`), runs its own qkv GEMM and the windows that

@@ -129,7 +129,9 @@ def make(name, autocast, H=None, W=None):
 
 
 @pytest.mark.parametrize("name,H,W,world", [("base_pad", None, None, 2), ("base_pad", 192, 96, 2),
-                                            ("base_pad", 192, 96, 3), ("base_pad", 192, 96, 4)])
+                                            ("base_pad", 192, 96, 3), ("base_pad", 192, 96, 4),
+                                            # thin bands: searched partitions (csrc/band.hip:band_rows)
+                                            ("base_pad", 256, 96, 4), ("base_pad", 256, 96, 5)])
 @pytest.mark.parametrize("autocast", [False, True])
 def test_sharded_equals_unsharded(name, H, W, world, autocast):
     model, batch = make(name, autocast, H, W)

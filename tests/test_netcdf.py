@@ -18,7 +18,7 @@ LEVELS = (100, 250, 500, 850)
 P = 4
 
 
-def _batch(H=48, W=32, seed=0):
+def _batch(H=192, W=32, seed=0):   # 48 patch rows: 12 at the coarsest stage, enough for three bands
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
     return Batch({k: r(1, 1, H, W) for k in ("2t", "msl")}, {k: r(H, W) for k in ("lsm", "z")},
@@ -46,7 +46,7 @@ def test_netcdf_round_trip(tmp_path):
 
 def test_band_needs_a_rank_field(tmp_path):
     b = _batch()
-    band = BandBatch(b.surf_vars, b.static_vars, b.atmos_vars, b.metadata, full_patch_rows=12, band=(0, 12))
+    band = BandBatch(b.surf_vars, b.static_vars, b.atmos_vars, b.metadata, full_patch_rows=48, band=(0, 48))
     with pytest.raises(ValueError, match="rank"):
         band.to_netcdf(tmp_path / "x.nc")
 
@@ -99,9 +99,9 @@ def test_band_files_carry_their_row_range(tmp_path):
     for p in netcdf.band_paths(tmp_path / "p.{rank}.nc"):
         _, coords, attrs = netcdf.read_dataset(p)
         rows.append(tuple(int(x) for x in np.atleast_1d(attrs["aurora_band_patch_rows"])))
-        assert int(attrs["aurora_full_patch_rows"]) == 12 and int(attrs["aurora_world"]) == 3
+        assert int(attrs["aurora_full_patch_rows"]) == 48 and int(attrs["aurora_world"]) == 3
         assert len(coords["latitude"]) == (rows[-1][1] - rows[-1][0]) * P
-    assert sorted(rows)[0][0] == 0 and sorted(rows)[-1][1] == 12
+    assert sorted(rows)[0][0] == 0 and sorted(rows)[-1][1] == 48
     _assert_same(Batch.from_netcdf([str(p) for p in netcdf.band_paths(tmp_path / "p.{rank}.nc")]), full)
 
 

@@ -128,7 +128,7 @@ def _gloo_worker(rank, world, port, res, shifted, ret):
         ops.append(dist.P2POp(dist.isend, t, q))
     for q, (off, cnt) in p.recv.items():
         ops.append(dist.P2POp(dist.irecv, halo[off:off + cnt], q))
-    for req in dist.batch_isend_irecv(ops):
+    for req in (dist.batch_isend_irecv(ops) if ops else []):   # (a split on a window row needs no exchange when un-shifted)
         req.wait()
     out = attention_numpy(torch.cat([own, halo]).numpy(), p.tok, p.grp, D, heads)
     band = np.stack([out[i] for i in range(p.n_own)])
@@ -146,7 +146,7 @@ def test_halo_exchange_over_two_gloo_processes(shifted):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = 29650 + int(shifted)
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, (4, 21, 24), shifted, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, (4, 22, 24), shifted, ret)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -215,6 +215,8 @@ def _c_plan(res, window, shifted, world, rank, rows):
 @pytest.mark.parametrize("res0,window,n_stages,world", [
     ((4, 180, 360), (2, 6, 12), 3, 8), ((4, 180, 360), (2, 6, 12), 3, 2), ((4, 150, 300), (2, 6, 12), 3, 4),
     ((4, 45, 90), (2, 6, 12), 3, 3), ((4, 12, 8), (2, 4, 4), 2, 3), ((2, 9, 6), (2, 3, 3), 1, 3),
+    # thin bands: the window-aligned split would need halo rows from a rank that is not a neighbour -> searched split
+    ((4, 150, 300), (2, 6, 12), 3, 8), ((4, 64, 24), (2, 6, 12), 3, 5), ((4, 56, 24), (2, 6, 12), 3, 6),
 ])
 def test_c_partition_and_plans_equal_the_numpy_ones(res0, window, n_stages, world):
     """csrc/band.hip (aurora_hip_band_partition / aurora_hip_band_plan) against partition.py, whose plans the tests above
@@ -243,6 +245,25 @@ def test_c_partition_and_plans_equal_the_numpy_ones(res0, window, n_stages, worl
                         assert info.recv_count[side] == 0
                     assert np.array_equal(sent, p.send.get(q, np.empty(0, np.int32)))
                 assert set(p.recv) <= {rank - 1, rank + 1} and set(p.send) <= {rank - 1, rank + 1}
+
+
+def test_thin_bands_get_a_searched_partition():
+    """The 0.4-degree grid on 8 ranks (BASELINE configs[4]): 38 coarsest-stage rows; the window-aligned split 6 x 5 + 3 + 3 + 2
+    lets a 6-row window reach past a 3-row band.  The search finds 7 x 5 + 3: every window within two neighbouring ranks,
+    largest band 5 of 38 rows (load-balance bound 0.95)."""
+    all_res, _ = geometry.stage_resolutions((4, 150, 300), 3)
+    rows = partition.band_rows(all_res, WINDOW, 8)
+    assert [h1 - h0 for h0, h1 in rows[-1]] == [5, 5, 5, 5, 5, 5, 5, 3]
+    assert [h1 - h0 for h0, h1 in rows[0]] == [20, 20, 20, 20, 20, 20, 20, 10]
+    for s, res in enumerate(all_res):
+        for shifted in (False, True):
+            for rank, p in enumerate(partition.block_plans(res, WINDOW, shifted, tuple(rows[s]))):
+                assert set(p.recv) <= {rank - 1, rank + 1} and set(p.send) <= {rank - 1, rank + 1}
+    # the grids whose window-aligned split works keep it (nothing validated so far changes)
+    era5, _ = geometry.stage_resolutions((4, 180, 360), 3)
+    assert [h1 - h0 for h0, h1 in partition.band_rows(era5, WINDOW, 8)[0]] == [24] * 7 + [12]
+    with pytest.raises(ValueError, match="too thin"):
+        partition.band_rows(geometry.stage_resolutions((4, 24, 24), 3)[0], WINDOW, 3)
 
 
 def test_c_partition_says_why_it_cannot_split():

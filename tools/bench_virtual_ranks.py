@@ -5,7 +5,7 @@ values that do not matter for timing).  sum over ranks = the GPU time of the who
 (un-sharded step) / sum is the compute efficiency of the partition (halo work, thin GEMMs, tile quantisation);
 max over ranks is what bounds a real R-GPU step from below.
 
-    python tools/bench_virtual_ranks.py [R ...]      (default 2 4 8)
+    python tools/bench_virtual_ranks.py [--model CLS --grid HxW] [R ...]      (default: AuroraPretrained 721x1440, R = 2 4 8)
 
 (tests/test_gpu_sharded.py runs the ranks TOGETHER, one thread each, with real halo copies: that checks results; its wall
 time includes the threads' waiting for each other and is not a compute measurement.)
@@ -49,11 +49,20 @@ def timed(fn, n=4):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-model = bench.build_model("cuda")
-batch = bench.synthetic_batch(model.config, 721, 1440, 1, "cuda").crop(model.patch_size)
+argv, cls_name, grid = sys.argv[1:], "AuroraPretrained", (721, 1440)
+while argv and argv[0].startswith("--"):
+    if argv[0] == "--model":
+        cls_name = argv[1]
+    elif argv[0] == "--grid":
+        grid = tuple(int(x) for x in argv[1].split("x"))
+    else:
+        raise SystemExit(f"unknown option {argv[0]}")
+    argv = argv[2:]
+model = bench.build_model("cuda", cls_name)
+batch = bench.synthetic_batch(model.config, grid[0], grid[1], 1, "cuda").crop(model.patch_size)
 single = timed(lambda: model.forward(batch))
-print(json.dumps({"ranks": 1, "ms_per_step": single}), flush=True)
-for R in [int(a) for a in sys.argv[1:]] or [2, 4, 8]:
+print(json.dumps({"model": cls_name, "grid": list(grid), "ranks": 1, "ms_per_step": single}), flush=True)
+for R in [int(a) for a in argv] or [2, 4, 8]:
     per_rank = []
     for r in range(R):
         model._shard = Shard(r, R, None, gather_output=False)
