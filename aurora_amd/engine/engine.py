@@ -150,45 +150,39 @@ class Engine:
         return h0.value, h1.value
 
     def _gather(self, pred: BandBatch) -> Batch:
-        """Assemble the full fields on every rank: each rank broadcasts its band into place."""
+        """Assemble the full fields on every rank with ONE collective: every field of the band is packed into one buffer
+        (bands padded to the tallest), all-gathered, and cut back into place."""
         import torch.distributed as dist
 
         sh, P = self.shard, self.cfg.patch_size
         W = pred.spatial_shape[1]
         rows0 = [self.band_rows_of(r, pred.full_patch_rows, W // P) for r in range(sh.world)]
-        H = rows0[-1][1] * P
-        to_global = (lambda r: dist.get_global_rank(sh.group, r)) if sh.group is not None else (lambda r: r)
-        staged = dist.get_backend(sh.group) == "gloo"
-
-        def bcast(piece, src):
-            if staged:
-                h = piece.cpu()
-                dist.broadcast(h, src=to_global(src), group=sh.group)
-                piece.copy_(h)
-            else:
-                dist.broadcast(piece, src=to_global(src), group=sh.group)
-
-        def gather(d_):
-            out = {}
-            for k, v in d_.items():
-                full = torch.empty((*v.shape[:-2], H, v.shape[-1]), dtype=v.dtype, device=v.device)
-                for r, (a, b) in enumerate(rows0):
-                    piece = v.contiguous() if r == sh.rank else torch.empty(
-                        (*v.shape[:-2], (b - a) * P, v.shape[-1]), dtype=v.dtype, device=v.device)
-                    bcast(piece, r)
-                    full[..., a * P:b * P, :] = piece
-                out[k] = full
-            return out
-
-        md = pred.metadata
-        lat_parts = []
-        for r, (a, b) in enumerate(rows0):
-            piece = md.lat.contiguous() if r == sh.rank else torch.empty((b - a) * P, dtype=md.lat.dtype,
-                                                                        device=md.lat.device)
-            bcast(piece, r)
-            lat_parts.append(piece)
-        return Batch(gather(pred.surf_vars), gather(pred.static_vars), gather(pred.atmos_vars),
-                     derive_metadata(md, lat=torch.cat(lat_parts)))
+        heights = [(b - a) * P for a, b in rows0]
+        h, h_max, H = heights[sh.rank], max(heights), rows0[-1][1] * P
+        groups = (pred.surf_vars, pred.static_vars, pred.atmos_vars)
+        items = [(gi, k, v) for gi, d_ in enumerate(groups) for k, v in d_.items()]
+        planes = [v.numel() // (h * W) for _, _, v in items]
+        mine = torch.zeros((sum(planes), h_max, W), dtype=F32, device=self.device)
+        at = 0
+        for (_, _, v), n in zip(items, planes):
+            mine[at:at + n, :h] = v.reshape(n, h, W)
+            at += n
+        if dist.get_backend(sh.group) == "gloo":   # tests: staged through host memory
+            parts = [torch.empty(mine.shape, dtype=F32) for _ in range(sh.world)]
+            dist.all_gather(parts, mine.cpu(), group=sh.group)
+            everyone = torch.stack(parts).to(self.device)
+        else:
+            everyone = torch.empty((sh.world, *mine.shape), dtype=F32, device=self.device)
+            dist.all_gather_into_tensor(everyone, mine, group=sh.group)
+        out: tuple[dict, dict, dict] = ({}, {}, {})
+        at = 0
+        for (gi, k, v), n in zip(items, planes):
+            full = torch.cat([everyone[r, at:at + n, :heights[r]] for r in range(sh.world)], dim=1)
+            out[gi][k] = full.reshape(*v.shape[:-2], H, W)
+            at += n
+        lat = self.native.full_lat()   # the whole (cropped) grid went through aurora_hip_precompute on every rank
+        assert lat is not None and lat.shape[0] == H, "the full grid's latitudes are unknown to this rank"
+        return Batch(out[0], out[1], out[2], derive_metadata(pred.metadata, lat=lat.to(pred.metadata.lat)))
 
     # -- per-launch timing (bench.py, tools): HIP events on the launch stream, inside the handle ---------------------
     def profile_start(self, only=None) -> None:

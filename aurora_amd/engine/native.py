@@ -253,6 +253,10 @@ class NativeModel:
         self._grid_ident = ident
         self._keep_coords = (lat, lon)
 
+    def full_lat(self):
+        """Latitudes of the whole grid last given to `precompute` (a sharded rank keeps them: its band is a slice)."""
+        return self._keep_coords[0] if getattr(self, "_keep_coords", None) is not None else None
+
     # -- per-launch timing (HIP events inside the handle, on the launch stream) -------------------------------------
     def profile_begin(self, only=None) -> None:
         mask = 0

@@ -241,7 +241,7 @@ def _proc(rank, world, port, ret, tmp):
 @pytest.mark.parametrize("world", [2, 3])
 def test_multiprocess_sharding_on_one_gpu(world, tmp_path):
     """The production code path (configure_sharding + forward / rollout, torch.distributed P2P halo
-    exchange, broadcast gather) with real processes; transport = gloo with host staging because
+    exchange, one all-gather of the packed prediction) with real processes; transport = gloo with host staging because
     several ranks share this box's single GPU (RCCL needs one GPU per rank)."""
     import torch.multiprocessing as mp
 
