@@ -276,3 +276,41 @@ def test_c_partition_says_why_it_cannot_split():
     h0, h1 = ctypes.c_int32(), ctypes.c_int32()
     assert L.aurora_hip_band_partition(3, i32((4, 8, 16)), i32((2, 6, 12)), 8, 0, 0, ctypes.byref(h0), ctypes.byref(h1)) == -1
     assert b"cannot split" in L.aurora_hip_last_error()
+
+
+def test_partition_search_properties():
+    """Random grids / rank counts: whenever a partition exists, csrc/band.hip and partition.py agree on it, the bands tile
+    the rows of every stage in order, 2 x 2 merges never straddle a rank, and every rank's halo rows come from its two
+    neighbours (in both block flavours at every stage)."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.integers(6, 70), st.integers(2, 8), st.integers(1, 3), st.sampled_from([(2, 6, 12), (2, 4, 4), (1, 3, 6)]))
+    def check(h0, world, n_stages, window):
+        res0 = (4, 2 * h0, 12)
+        all_res, _ = geometry.stage_resolutions(res0, n_stages)
+        try:
+            want = partition.band_rows(all_res, window, world)
+        except ValueError:
+            h_a, h_b = ctypes.c_int32(), ctypes.c_int32()
+            rc = L.aurora_hip_band_partition(n_stages, i32(res0), i32(window), world, 0, 0, ctypes.byref(h_a), ctypes.byref(h_b))
+            assert rc == -1     # the library refuses the same cases
+            return
+        assert _c_rows(n_stages, res0, window, world) == [[tuple(r) for r in rows] for rows in want]
+        for s, res in enumerate(all_res):
+            rows = want[s]
+            assert rows[0][0] == 0 and rows[-1][1] == res[1] and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+            if s + 1 < len(all_res):
+                assert all(h1 % 2 == 0 for _, h1 in rows[:-1])    # a merge pair (2k, 2k + 1) belongs to one rank
+            for shifted in (False, True):
+                for rank, p in enumerate(partition.block_plans(tuple(res), tuple(window), shifted, tuple(rows))):
+                    assert set(p.recv) <= {rank - 1, rank + 1} and set(p.send) <= {rank - 1, rank + 1}
+
+    import ctypes
+
+    from aurora_amd.engine import lib
+
+    L = lib.load()
+    i32 = lambda v: (ctypes.c_int32 * len(v))(*v)  # noqa: E731
+    check()
