@@ -27,7 +27,20 @@ struct PatchArgs {
   PatchVar v[MAX_VARS];
   void* out; int64_t Kpad; int k_offset; int K_total;
   int n_vars, B, T, n_lvl, Hp, Wp, P;
+  float* absmax;   // nullable: max |value written| is folded into this word (non-negative floats order like their bits)
 };
+
+// max over the wave, then at most one atomic per wave -- and only if it can still raise the word (a relaxed look first):
+// the guard word of the encoder's operand-split decision (step.hip) costs the producer of the values nothing but this,
+// where a separate absmax pass re-read all of them (0.6 GB per step at 0.25 degree).
+__device__ __forceinline__ void fold_absmax(float* word, float m) {
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned int bits = __float_as_uint(m);
+    if (bits > __hip_atomic_load(reinterpret_cast<unsigned int*>(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<unsigned int*>(word), bits);
+  }
+}
 
 __device__ __forceinline__ float patch_transform(float z, const PatchVar& d) {
   if (d.transform == 1) return fmaxf(z, 0.f);
@@ -55,7 +68,10 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
   const int64_t rows = (int64_t)p.n_lvl * p.B * L;
   const int q_per_row = p.n_vars * p.T * p.P;
   const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= rows * q_per_row) return;
+  if (item >= rows * q_per_row) {   // (whole waves of the last block, or its last wave's tail: they still join the reduction)
+    if (p.absmax) fold_absmax(p.absmax, 0.f);
+    return;
+  }
   const int64_t row = item / q_per_row;
   const int q = (int)(item - row * q_per_row);
   const int i = q % p.P;
@@ -72,8 +88,10 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
   {
     // patch size 4, fp32 operand, aligned (checked by the launcher): one 16-byte load and one 16-byte store per thread
     const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
-    *reinterpret_cast<f32x4*>(dst) = f32x4{patch_transform((s4.x - loc) * inv, d), patch_transform((s4.y - loc) * inv, d),
-                                            patch_transform((s4.z - loc) * inv, d), patch_transform((s4.w - loc) * inv, d)};
+    const f32x4 r4 = f32x4{patch_transform((s4.x - loc) * inv, d), patch_transform((s4.y - loc) * inv, d),
+                           patch_transform((s4.z - loc) * inv, d), patch_transform((s4.w - loc) * inv, d)};
+    *reinterpret_cast<f32x4*>(dst) = r4;
+    if (p.absmax) fold_absmax(p.absmax, fmaxf(fmaxf(fabsf(r4.x), fabsf(r4.y)), fmaxf(fabsf(r4.z), fabsf(r4.w))));
   }
   // zero the K padding of this row (done by the threads of the last variable's last piece)
   if (q == q_per_row - 1 && p.k_offset + q_per_row * p.P == p.K_total) {
@@ -100,7 +118,10 @@ __global__ __launch_bounds__(256) void patchify_cols_kernel(const PatchArgs p, c
   const int n_k = k_end - p.k_offset;
   const unsigned wp = blockIdx.x / (unsigned)chunks, chunk = blockIdx.x - wp * (unsigned)chunks;
   const int kk = (int)(chunk * 256u + threadIdx.x);
-  if (kk >= n_k) return;
+  if (kk >= n_k) {
+    if (p.absmax) fold_absmax(p.absmax, 0.f);
+    return;
+  }
   const unsigned hp = blockIdx.y;
   const unsigned c = blockIdx.z / (unsigned)p.B, b = blockIdx.z - c * (unsigned)p.B;
   const int64_t row = ((int64_t)blockIdx.z * p.Hp + hp) * p.Wp + wp;   // rows are (level, batch, patch)
@@ -109,6 +130,7 @@ __global__ __launch_bounds__(256) void patchify_cols_kernel(const PatchArgs p, c
   const unsigned vt = (unsigned)kk / PP;
   if ((int)vt >= p.n_vars * p.T) {   // K padding
     elem<T>::store(dst, 0.f);
+    if (p.absmax) fold_absmax(p.absmax, 0.f);
     return;
   }
   const unsigned ij = (unsigned)kk - vt * PP;
@@ -117,7 +139,9 @@ __global__ __launch_bounds__(256) void patchify_cols_kernel(const PatchArgs p, c
   const PatchVar& d = p.v[v];
   const float z = (d.src[b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)(wp * p.P + j) * d.sw] - d.loc[c]) *
                   d.inv_scale[c];
-  elem<T>::store(dst, patch_transform(z, d));
+  const float r = patch_transform(z, d);
+  elem<T>::store(dst, r);
+  if (p.absmax) fold_absmax(p.absmax, fabsf(r));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -348,6 +372,12 @@ using namespace aurora;
 extern "C" int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, void* out, int64_t Kpad,
                                    int k_offset, int K_total, int B, int T, int n_lvl, int Hp, int Wp, int P,
                                    int dtype, void* stream) {
+  return aurora_hip_patchify_absmax(desc, n_vars, out, Kpad, k_offset, K_total, B, T, n_lvl, Hp, Wp, P, dtype, nullptr, stream);
+}
+
+extern "C" int aurora_hip_patchify_absmax(const aurora_patch_var* desc, int n_vars, void* out, int64_t Kpad,
+                                          int k_offset, int K_total, int B, int T, int n_lvl, int Hp, int Wp, int P,
+                                          int dtype, float* absmax, void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "patchify: bad dtype");
   AURORA_CHECK_ARG(n_vars > 0 && n_vars <= MAX_VARS, "patchify: %d variables per call (max %d)", n_vars, MAX_VARS);
   AURORA_CHECK_ARG(k_offset >= 0 && k_offset + n_vars * T * P * P <= K_total && K_total <= Kpad,
@@ -361,6 +391,7 @@ extern "C" int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, voi
   }
   p.out = out; p.Kpad = Kpad; p.k_offset = k_offset; p.K_total = K_total;
   p.n_vars = n_vars; p.B = B; p.T = T; p.n_lvl = n_lvl; p.Hp = Hp; p.Wp = Wp; p.P = P;
+  p.absmax = absmax;
   const int64_t items = (int64_t)n_lvl * B * Hp * Wp * n_vars * T * P;
   AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "patchify: bad problem size");
   bool vec4 = P == 4 && dtype == AURORA_F32 && (uintptr_t)out % 16 == 0 && Kpad % 4 == 0 && k_offset % 4 == 0;

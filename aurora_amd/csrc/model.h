@@ -209,9 +209,13 @@ struct aurora_hip_model {
   void* stage_recv = nullptr;
   int64_t staging_bytes = 0, staging_need = 0;
   bool sharded() const { return band.world > 1; }
+  // process defaults read ONCE, when the handle is created (never inside a step): AURORA_FUSE_LN, AURORA_BAND_SPLIT_ATTENTION
+  int fuse_ln = 1;
+  bool split_attention = false;
 
   // per step
   aurora::DevBuf abs_enc, dyn_planes, ctx_max;
+  aurora::DevBuf tickets;   // split-K tickets of aurora_hip_linear_ws: SPLIT_TICKETS zeroed words, left zero by every launch
   int abs_B = 0;
   struct Pinned { float* host = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; };
   Pinned pinned[4];     // staging ring of aurora_hip_set_time: an upload never waits for the previous step
@@ -279,6 +283,8 @@ void timed(Model& m, void* stream, int kind, double work, F&& fn) {
   }
 }
 
+constexpr int SPLIT_TICKETS = 4096;
+
 // launches (skipped in a dry run)
 struct Launcher {
   Model& m;
@@ -288,13 +294,23 @@ struct Launcher {
               int N, int K, int dtype, int act = AURORA_ACT_NONE, void* C2 = nullptr, int64_t ldc2 = 0,
               const float* res = nullptr, int64_t ldr = 0, int f32_gemm = -1, const float* guard = nullptr,
               float limit = 0.f, int batch = 1, int64_t sa = 0, int64_t sw = 0, int64_t sbias = 0, int64_t sc = 0) {
+    // plain bf16 linears with few tiles and a long K borrow slab scratch from the arena and split along K (gemm.hip)
+    void* ws = nullptr;
+    int64_t ws_bytes = 0;
+    const size_t mark = m.arena.top;
+    if (dtype == AURORA_BF16 && batch == 1 && f32_gemm == -1 && (ws_bytes = aurora_hip_linear_workspace(M, N, K, dtype)) > 0)
+      ws = m.arena.take((size_t)ws_bytes);
     timed(m, stream, dtype == AURORA_BF16 ? K_LINEAR_BF16 : K_LINEAR_F32, 2.0 * (double)M * N * K * batch, [&] {
+      if (ws)
+        return aurora_hip_linear_ws(A, lda, Wt, ldw, bias, C, ldc, C2, ldc2, res, ldr, M, N, K, dtype, act, ws, ws_bytes,
+                                    (int32_t*)m.tickets.p, SPLIT_TICKETS, 0, stream);
       if (batch > 1)
         return aurora_hip_linear_batched(A, lda, Wt, ldw, bias, C, ldc, M, N, K, dtype, act, f32_gemm, guard, limit, batch, sa,
                                          sw, sbias, sc, stream);
       return aurora_hip_linear_ex(A, lda, Wt, ldw, bias, C, ldc, C2, ldc2, res, ldr, M, N, K, dtype, act, f32_gemm, guard,
                                   limit, stream);
     });
+    m.arena.top = mark;   // (stream order: the next launch that takes this memory runs after this one)
   }
   void layernorm(const void* y, int64_t ldy, const float* gain, const float* shift, const float* res, int64_t ldr,
                  int64_t res_mod, float* out_f32, int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D, float eps,

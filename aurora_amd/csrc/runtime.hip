@@ -117,9 +117,28 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 }  // namespace
 }  // namespace aurora
 
+namespace aurora {
+namespace {
+__global__ void zero_words_kernel(float* w, int n) {
+  if ((int)threadIdx.x < n) w[threadIdx.x] = 0.f;
+}
+}  // namespace
+}  // namespace aurora
+
+extern "C" int aurora_hip_zero_words(float* words, int n, void* stream) {
+  AURORA_CHECK_ARG(words != nullptr && n > 0 && n <= 64, "zero_words: 1 <= n <= 64");
+  hipLaunchKernelGGL(aurora::zero_words_kernel, dim3(1), dim3(64), 0, as_stream(stream), words, n);
+  return check_launch("zero_words");
+}
+
 extern "C" int aurora_hip_absmax(const float* x, int64_t n, float* out, void* stream) {
+  AURORA_CHECK_ARG(out != nullptr, "absmax: bad arguments");
+  const int rc = aurora_hip_zero_words(out, 1, stream);
+  return rc != AURORA_OK ? rc : aurora_hip_absmax_fold(x, n, out, stream);
+}
+
+extern "C" int aurora_hip_absmax_fold(const float* x, int64_t n, float* out, void* stream) {
   AURORA_CHECK_ARG(x != nullptr && out != nullptr && n > 0 && (uintptr_t)x % 16 == 0, "absmax: bad arguments");
-  if (hipMemsetAsync(out, 0, sizeof(float), as_stream(stream)) != hipSuccess) return AURORA_E_LAUNCH;
   const int64_t n4 = n / 4;
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 + 1 : 2048);
   hipLaunchKernelGGL(aurora::absmax_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, n4, n, out);

@@ -17,15 +17,18 @@ struct CtxGuard { const float* word; float a, c, limit_kv; bool pairs; };
 // b*kv_bstride + j*kv_lstride + l.  First layer: latents (and so q) are shared by every column.  Returns (B*cols*Lq, D).
 float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, int64_t ctx_rows, int ctx_dim, const float* q0,
                  const float* latents0, int B, int64_t cols, int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads,
-                 float eps, size_t& out_mark, const CtxGuard* cg = nullptr, bool out_pairs = false) {
+                 float eps, size_t& out_mark, const CtxGuard* cg = nullptr, bool out_pairs = false, int own_word = 0) {
   const int64_t n_rows = (int64_t)B * cols * Lq;
   // The context is as unbounded as the model inputs, so the linears that read it, or averages of its value projection,
   // pick their operand split on the device: from max |ctx|, measured here, or from the bound the caller derived from a
   // word it measured upstream (`cg`).
-  const float* ctx_max = cg ? cg->word : m.ctx_max.f();
+  const float* ctx_max = cg ? cg->word : m.ctx_max.f() + own_word;
   const float g_a = cg ? cg->a : 1.0f, g_c = cg ? cg->c : 0.0f;
   const bool ctx_pairs = cg && cg->pairs;
-  if (!cg) timed(m, L.stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(ctx, ctx_rows * ctx_dim, m.ctx_max.f(), L.stream); });
+  // (the words were cleared at the start of the step; the two decoder Perceivers of a `separate_perceiver` model scan the
+  // same context into the same word)
+  if (!cg)
+    timed(m, L.stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax_fold(ctx, ctx_rows * ctx_dim, m.ctx_max.f() + own_word, L.stream); });
   float* lat = nullptr;
   for (size_t i = 0; i < rs.layers.size(); ++i) {
     const auto& ly = rs.layers[i];
@@ -209,6 +212,10 @@ void run_step(Model& m, const StepIO& s, void* stream) {
   const int new_step = io.rollout_step + 1;
   const bool clamp_now = m.clamp_first ? new_step >= 1 : new_step > 1;   // aurora.py:368-388
 
+  // the four guard words of the step's operand-split decisions (0: encoder context when it is not part of the guarded
+  // chain, 1: atmospheric / 2: surface patch-embedding inputs, 3: decoder context), cleared by ONE launch; their producers
+  // fold the maxima in (patchify) or scan (absmax_fold)
+  if (!m.dry) ok(aurora_hip_zero_words(m.ctx_max.f(), 4, stream));
   // ================= encoder (encoder.py:198-366) =================
   float* x_f = (float*)A.take((size_t)B * Cl * Lp * D * 4);                      // residual stream of stage 0 (fp32)
   void* x_b = m.autocast ? A.take((size_t)B * Cl * Lp * D * 2) : nullptr;        // bf16 shadow (GEMM operand)
@@ -223,10 +230,12 @@ void run_step(Model& m, const StepIO& s, void* stream) {
     float* A_s = (float*)A.take((size_t)B * Lp * Kpad_s * 4);
     std::vector<aurora_patch_var> descs;
     for (int ci : ps.channels) descs.push_back(channel_desc(m, io, m.surf_channels[ci], false, C));
+    const bool surf_guarded = m.surf_chain && ps.ws.p != nullptr;
     for (size_t i = 0; i < descs.size(); i += 32)
       timed(m, stream, K_PATCHIFY, 0.0, [&] {
-        return aurora_hip_patchify(descs.data() + i, (int)std::min<size_t>(32, descs.size() - i), A_s, Kpad_s, (int)i * T * PP,
-                                   K_s, B, T, 1, Hp, Wp, P, AURORA_F32, stream);
+        return aurora_hip_patchify_absmax(descs.data() + i, (int)std::min<size_t>(32, descs.size() - i), A_s, Kpad_s,
+                                          (int)i * T * PP, K_s, B, T, 1, Hp, Wp, P, AURORA_F32,
+                                          surf_guarded ? m.ctx_max.f() + 2 : nullptr, stream);
       });
     float* xs0 = (float*)A.take((size_t)B * Lp * D * 4);
     const int hid_s = (int)m.T_("encoder.surf_mlp.net.0.weight").shape[0];
@@ -236,9 +245,8 @@ void run_step(Model& m, const StepIO& s, void* stream) {
     // bound that word implies for ITS activation operand is inside fp16's range -- embedding: the input itself; first
     // MLP linear: |xs0| <= l1_e * w + c; second: |GELU(h)| <= |h| <= l1_0 * (l1_e * w + c) + |b0| -- else three bf16 terms.
     const void* w_s_s = ps.ws.p;
-    if (m.surf_chain && w_s_s) {
-      float* word = m.ctx_max.f() + 2;
-      timed(m, stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(A_s, (int64_t)B * Lp * Kpad_s, word, stream); });
+    if (surf_guarded) {
+      float* word = m.ctx_max.f() + 2;   // max |normalised surface input|, folded in by patchify above
       const float l1e = ps.l1;
       const float lim_e = F16_SAFE, lim_0 = (F16_SAFE - m.surf_c) / l1e, lim_2 = ((F16_SAFE - m.surf_b0) / m.surf_l1_0 - m.surf_c) / l1e;
       auto pair = [&](const float* a, int64_t lda, const float* wf, const void* ws, const float* bias, float* c, int64_t ldc, int N_,
@@ -271,10 +279,14 @@ void run_step(Model& m, const StepIO& s, void* stream) {
     float* A_a = (float*)A.take((size_t)C * B * Lp * Kpad_a * 4);
     std::vector<aurora_patch_var> adescs;
     for (int ci : pa.channels) adescs.push_back(channel_desc(m, io, m.atmos_channels[ci], true, C));
+    const void* w_a_s = pa.ws.p;
+    bool chain = w_a_s != nullptr;
+    for (const auto& ly : m.enc_rs.layers) chain = chain && ly.f16_mode == 2 && ly.to_kv_s != nullptr;
     for (size_t i = 0; i < adescs.size(); i += 32)
       timed(m, stream, K_PATCHIFY, 0.0, [&] {
-        return aurora_hip_patchify(adescs.data() + i, (int)std::min<size_t>(32, adescs.size() - i), A_a, Kpad_a,
-                                   (int)i * T * PP, K_a, B, T, C, Hp, Wp, P, AURORA_F32, stream);
+        return aurora_hip_patchify_absmax(adescs.data() + i, (int)std::min<size_t>(32, adescs.size() - i), A_a, Kpad_a,
+                                          (int)i * T * PP, K_a, B, T, C, Hp, Wp, P, AURORA_F32,
+                                          chain ? m.ctx_max.f() + 1 : nullptr, stream);
       });
     float* xa = (float*)A.take((size_t)C * B * Lp * D * 4);
     const int64_t R = (int64_t)B * Lp;
@@ -285,14 +297,10 @@ void run_step(Model& m, const StepIO& s, void* stream) {
     // three bf16 terms over fp32 buffers.  One word and one limit decide format and kernels together.
     // All C levels are ONE strided-batch launch: level c reads rows [c R, (c + 1) R) of the unfolded input, its own bias
     // (level embedding + patch bias) and -- level-conditioned models (levelcond.py:36-69) -- its own weight.
-    const void* w_a_s = pa.ws.p;
-    bool chain = w_a_s != nullptr;
-    for (const auto& ly : m.enc_rs.layers) chain = chain && ly.f16_mode == 2 && ly.to_kv_s != nullptr;
     CtxGuard cg{};
     const int64_t sw = pa.groups > 1 ? (int64_t)D * Kpad_a : 0;
     if (chain) {
-      float* word = m.ctx_max.f() + 1;
-      timed(m, stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax(A_a, (int64_t)C * R * Kpad_a, word, stream); });
+      float* word = m.ctx_max.f() + 1;   // max |normalised atmospheric input|, folded in by patchify above
       const float l1 = pa.l1, cb = m.enc_bias_max;
       cg = CtxGuard{word, l1, cb, std::min(F16_SAFE, (F16_SAFE - cb) / l1), true};
       L.linear(A_a, Kpad_a, w_a_s, Kpad_a, m.enc_bias.f(), xa, D, R, D, Kpad_a, AURORA_F32, 0, nullptr, 0, nullptr, 0,
@@ -398,7 +406,12 @@ void run_step(Model& m, const StepIO& s, void* stream) {
         }
         L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
         if (exchange) {
-          if (pl.n_interior > 0) attend(qkv, tok, grp, pl.n_interior, pl.n_tok, Lq, Ls);
+          // The halo rows were posted ahead of the qkv GEMM above, so the transfer has that whole GEMM to hide under.  By
+          // default ALL windows then run in one launch behind the halo projection: a band's interior / boundary launches
+          // are latency-bound (~15 us each for a few hundred workgroups), two of them cost a rank 0.4 ms per step.
+          // `split_attention` (AURORA_BAND_SPLIT_ATTENTION=1 at creation) keeps the interior windows as a launch of their
+          // own in front of `wait`, for transports that need those extra microseconds of cover.
+          if (m.split_attention && pl.n_interior > 0) attend(qkv, tok, grp, pl.n_interior, pl.n_tok, Lq, Ls);
           if (!m.dry) {
             const int rc = m.band.wait(m.band.user, stream);
             REQUIRE(rc == 0, "the host's halo `wait` callback failed (%d)", rc);
@@ -410,17 +423,16 @@ void run_step(Model& m, const StepIO& s, void* stream) {
           if (n_recv > 0)
             L.linear(m.stage_recv, dim, w_kv, dim, blk.qkv_b + dim, qkv + ((size_t)(Ls + first) * 3 * dim + dim) * es, 3 * dim, n_recv,
                      2 * dim, dim, bb);
-          if (pl.n_windows > pl.n_interior)
-            attend(qkv, tok + (size_t)pl.n_interior * pl.n_tok, grp ? grp + (size_t)pl.n_interior * pl.n_tok : nullptr,
-                   pl.n_windows - pl.n_interior, pl.n_tok, Lq, Ls);
+          const int w0 = (m.split_attention && pl.n_interior > 0) ? pl.n_interior : 0;
+          if (pl.n_windows > w0)
+            attend(qkv, tok + (size_t)w0 * pl.n_tok, grp ? grp + (size_t)w0 * pl.n_tok : nullptr, pl.n_windows - w0, pl.n_tok, Lq, Ls);
         } else {
           attend(qkv, tok, grp, pl.n_windows, pl.n_tok, Lq, Ls);
         }
       }
       // D = 512 under autocast: the linear, its AdaLN and the residual add are ONE launch (a workgroup owns whole rows)
-      // AURORA_FUSE_LN: 0 never, 1 (default) by the fill rule below, 2 always (tests: read per step, not cached)
-      const char* fuse_e = getenv("AURORA_FUSE_LN");
-      const int fuse_env = fuse_e ? atoi(fuse_e) : 1;
+      // m.fuse_ln (AURORA_FUSE_LN when the handle was created): 0 never, 1 (default) by the fill rule below, 2 always
+      const int fuse_env = m.fuse_ln;
       // (a row-owning tile is 128 rows: only when the launch fills its rounds of one tile per CU -- a latitude band's
       // 270 tiles on 256 CUs would take two rounds for the work of 1.05)
       const int64_t ln_tiles = (M + 127) / 128, cus = device_cus();
@@ -615,7 +627,7 @@ void run_step(Model& m, const StepIO& s, void* stream) {
       const bool two_term = hg.n_pad > 0 && last_pairs && (gi == 0 ? m.dec_out_bound : m.dec_out_bound_alt) < F16_SAFE;
       size_t rs_mark = 0;
       float* lat = resampler(m, L, rs, ctx, (int64_t)B * (Cl - 1) * Lp, D2, groups[gi].q, m.dec_queries.f(), B, Lp,
-                             (int64_t)(Cl - 1) * Lp, Lp, C, Cl - 1, m.perceiver_heads, m.ln_eps, rs_mark, nullptr, two_term);
+                             (int64_t)(Cl - 1) * Lp, Lp, C, Cl - 1, m.perceiver_heads, m.ln_eps, rs_mark, nullptr, two_term, 3);
       const int n_a = two_term ? hg.n_pad : (int)hg.names.size() * PP, ld_a = round_up(n_a, 4);
       const float* hw = two_term ? (const float*)hg.ws.p : hg.w.f();
       const float* hb = two_term ? hg.bs.f() : hg.b.f();

@@ -54,10 +54,16 @@ _SIGNATURES = {
     "aurora_hip_linear_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                      c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                      c_int, c_int, c_void_p, c_float, c_void_p]),
+    "aurora_hip_linear_workspace": (c_int64, [c_int64, c_int, c_int, c_int]),
+    "aurora_hip_linear_ws": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                     c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p,
+                                     c_int, c_int, c_void_p]),
     "aurora_hip_linear_batched": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                           c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_int64, c_int64, c_int64,
                                           c_int64, c_void_p]),
     "aurora_hip_absmax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "aurora_hip_absmax_fold": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "aurora_hip_zero_words": (c_int, [c_void_p, c_int, c_void_p]),
     "aurora_hip_linear_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_float,
                                             c_void_p]),
@@ -80,6 +86,8 @@ _SIGNATURES = {
                                     c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "aurora_hip_patchify": (c_int, [ctypes.POINTER(PatchVar), c_int, c_void_p, c_int64, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "aurora_hip_patchify_absmax": (c_int, [ctypes.POINTER(PatchVar), c_int, c_void_p, c_int64, c_int, c_int,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "aurora_hip_perceiver_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64,
                                                c_int64, c_int64, c_int, c_int, c_int, c_int, c_int,
                                                c_void_p]),
@@ -326,6 +334,34 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: 
     return out
 
 
+def linear_workspace(M: int, N: int, K: int, dtype: torch.dtype = torch.bfloat16) -> int:
+    """Bytes of scratch `linear_ws` would like for this shape (0: the library would not split it along K)."""
+    return int(load().aurora_hip_linear_workspace(M, N, K, dtype_code(dtype)))
+
+
+def linear_ws(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, workspace: torch.Tensor,
+              tickets: torch.Tensor, *, split: int = 0, out2: Optional[torch.Tensor] = None,
+              residual: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
+    """`linear` with lent scratch: few-tile / long-K bf16 problems are split along K inside one launch (aurora_hip_linear_ws).
+    `workspace`: any contiguous tensor; `tickets`: int32, zero on entry, left zero.  split = 0 lets the library choose."""
+    lda, K = _rows(a)
+    ldw, _ = _rows(w)
+    M, N = a.shape[0], w.shape[0]
+    assert a.dtype == w.dtype == out.dtype and tickets.dtype == torch.int32 and workspace.is_contiguous()
+    ldc, _ = _rows(out)
+    ldc2 = ldr = 0
+    if out2 is not None:
+        ldc2, _ = _rows(out2)
+    if residual is not None:
+        ldr, _ = _rows(residual)
+    with _Timed("linear_bf16" if a.dtype == torch.bfloat16 else "linear_f32", 2.0 * M * N * K):
+        _check(load().aurora_hip_linear_ws(_ptr(a), lda, _ptr(w), ldw, _ptr(bias), _ptr(out), ldc, _ptr(out2), ldc2,
+                                           _ptr(residual), ldr, M, N, K, dtype_code(a.dtype), act, _ptr(workspace),
+                                           workspace.numel() * workspace.element_size(), _ptr(tickets), tickets.numel(), split,
+                                           _stream()))
+    return out
+
+
 def linear_layernorm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], gain: Optional[torch.Tensor],
                      shift: Optional[torch.Tensor], x: torch.Tensor, x_out: torch.Tensor,
                      x_bf16: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
@@ -424,13 +460,15 @@ def split_ln(y: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, out: torch
 
 
 def patchify(desc: list[PatchVar], out: torch.Tensor, k_offset: int, k_total: int, B: int, T: int,
-             n_lvl: int, Hp: int, Wp: int, P: int) -> None:
+             n_lvl: int, Hp: int, Wp: int, P: int, absmax: Optional[torch.Tensor] = None) -> None:
+    """`absmax` (one fp32 word, NOT zeroed here): max |value written| is folded into it."""
     Kpad = out.shape[1]
     assert out.is_contiguous() and out.shape[0] == n_lvl * B * Hp * Wp
+    assert absmax is None or (absmax.dtype == torch.float32 and absmax.numel() >= 1)
     arr = (PatchVar * len(desc))(*desc)
     with _Timed("patchify", 0.0):
-        _check(load().aurora_hip_patchify(arr, len(desc), _ptr(out), Kpad, k_offset, k_total, B, T, n_lvl,
-                                          Hp, Wp, P, dtype_code(out.dtype), _stream()))
+        _check(load().aurora_hip_patchify_absmax(arr, len(desc), _ptr(out), Kpad, k_offset, k_total, B, T, n_lvl,
+                                                 Hp, Wp, P, dtype_code(out.dtype), _ptr(absmax), _stream()))
 
 
 def perceiver_attention(q: torch.Tensor, q_col_stride: int, kv: torch.Tensor, out: torch.Tensor,

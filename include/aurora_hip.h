@@ -86,6 +86,24 @@ int aurora_hip_linear_batched(const void* A, int64_t lda, const void* W, int64_t
                               float guard_limit, int batch, int64_t stride_a, int64_t stride_w, int64_t stride_bias,
                               int64_t stride_c, void* stream);
 
+/* aurora_hip_linear for callers that can lend scratch memory: a bf16 linear with few 256 x 256 tiles and a long K (the
+ * per-rank shapes of a latitude band at the coarse backbone stages, swin3d.py:59-66,153,169 at M = 2,160: 72 tiles on
+ * 256 CUs, K = 8192) is then split along K inside ONE launch -- every tile's K range is cut into `split` slices, one
+ * workgroup each; slices publish their fp32 accumulators to `workspace` and take a ticket of their tile, and whoever
+ * draws a tile's last ticket adds the slices up in slice order and runs the epilogue.  No workgroup waits for another
+ * (nothing depends on dispatch order), the result does not depend on arrival order; it differs from the un-split
+ * product by the rounding of split - 1 fp32 additions per element.
+ *   aurora_hip_linear_workspace: bytes of scratch the library would like for this shape (0: it would not split).
+ *   workspace, workspace_bytes : 16-byte aligned scratch, contents irrelevant; too small / NULL = no split.
+ *   tickets, n_tickets         : int32 words, ZERO on entry and left zero (one per tile); fewer than tiles = no split.
+ *   split                      : 0 lets the library choose, 1 forbids, > 1 asks for that many slices.
+ * fp32 problems and shapes that would not split run exactly as aurora_hip_linear. */
+int64_t aurora_hip_linear_workspace(int64_t M, int N, int K, int dtype);
+int aurora_hip_linear_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                         void* C2, int64_t ldc2, const float* residual, int64_t ldr, int64_t M, int N, int K, int dtype,
+                         int act, void* workspace, int64_t workspace_bytes, int32_t* tickets, int n_tickets, int split,
+                         void* stream);
+
 /* Mode 2 with operands that are ALREADY split (flags OR-ed into f32_gemm = 2): the split is the same arithmetic wherever
  * it happens, so results are bit-identical to plain mode 2, but a GEMM whose operands arrive split spends no VALU work
  * on them -- the two-term kernel goes from 0.29 to 0.40 PFLOP/s fp32-equivalent when both do.
@@ -107,8 +125,13 @@ int aurora_hip_linear_batched(const void* A, int64_t lda, const void* W, int64_t
 int aurora_hip_split_f16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int K,
                          float scale, void* stream);
 
-/* out[0] = max |x[i]| over n contiguous fp32 values (x 16-byte aligned); NaNs are ignored. */
+/* out[0] = max |x[i]| over n contiguous fp32 values (x 16-byte aligned); NaNs are ignored.
+ * aurora_hip_absmax_fold: out[0] = max(out[0], max |x[i]|) -- no zeroing, so that several producers can share one word;
+ * aurora_hip_zero_words clears n <= 64 such words with one tiny launch (a step clears all of its guard words at once:
+ * a 4-byte hipMemsetAsync in front of every absmax cost a latitude band ~90 us each). */
 int aurora_hip_absmax(const float* x, int64_t n, float* out, void* stream);
+int aurora_hip_absmax_fold(const float* x, int64_t n, float* out, void* stream);
+int aurora_hip_zero_words(float* words, int n, void* stream);
 
 /* ---- 3D shifted-window attention core ------------------------------------------------------
  * For every window w and head h: O = softmax(Q K^T / sqrt(hd) + mask) V over the window's
@@ -211,6 +234,11 @@ typedef struct aurora_patch_var {
 int aurora_hip_patchify(const aurora_patch_var* desc, int n_vars, void* out, int64_t Kpad,
                         int k_offset, int K_total, int B, int T, int n_lvl, int Hp, int Wp, int P,
                         int dtype, void* stream);
+/* The same, and max |value written| is folded into *absmax (nullable; not zeroed here: aurora_hip_zero_words) -- the
+ * guard word of the operand-split decision of the linears that read `out` (aurora_hip_linear_ex), at no extra pass. */
+int aurora_hip_patchify_absmax(const aurora_patch_var* desc, int n_vars, void* out, int64_t Kpad,
+                               int k_offset, int K_total, int B, int T, int n_lvl, int Hp, int Wp, int P,
+                               int dtype, float* absmax, void* stream);
 
 /* ---- small-set cross attention of the Perceiver resamplers ---------------------------------
  * Per grid column col in [0, n_cols) and head: softmax(q k^T / sqrt(hd)) v over Lk keys.
