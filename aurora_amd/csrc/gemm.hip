@@ -66,6 +66,7 @@ struct LinearArgs {
   // split-K (linear_kernel_256pp, MODE 1): workgroup b multiplies K-slice b / n_blocks of tile b % n_blocks; slices
   // meet through fp32 slabs (256 KiB per slice and tile) and a ticket per tile -- the last arriver adds up and finishes
   int split; float* slabs; int32_t* tickets;
+  int gn;   // linear_kernel_256pp: n-tiles per group of the tile order
 };
 
 // The problem of a strided batch this workgroup belongs to (blockIdx.y; a plain launch has one problem and zero strides).
@@ -341,6 +342,26 @@ __device__ __forceinline__ void tile_of_block(uint32_t bid, uint32_t nb, uint32_
     tile_n = grp * GN + (rem - tile_m * GN);
   } else {                                             // last, narrower group
     const uint32_t rem = logical - (full / GN) * per_group, gw = tiles_n - full;
+    tile_m = rem / gw;
+    tile_n = full + (rem - tile_m * gw);
+  }
+}
+
+// The same order with the width of an n-group chosen per launch (linear_kernel_256pp: an XCD's round of 32 concurrent
+// tiles is (32 / gn) m-tiles x gn n-tiles; at K >= 1024 the 8 weight panels of gn = 8 no longer survive in the 4 MiB L2
+// from one round to the next, a narrower group's do).
+__device__ __forceinline__ void tile_of_block_gn(uint32_t gn, uint32_t bid, uint32_t nb, uint32_t tiles_m, uint32_t tiles_n,
+                                                 uint32_t& tile_m, uint32_t& tile_n) {
+  const uint32_t q8 = nb >> 3, r8 = nb & 7;
+  const uint32_t xcd = bid & 7, idx = bid >> 3;
+  const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const uint32_t groups = tiles_n / gn, full = groups * gn, per_group = gn * tiles_m;
+  if (logical < groups * per_group) {
+    const uint32_t grp = logical / per_group, rem = logical - grp * per_group;
+    tile_m = rem / gn;
+    tile_n = grp * gn + (rem - tile_m * gn);
+  } else {
+    const uint32_t rem = logical - groups * per_group, gw = tiles_n - full;
     tile_m = rem / gw;
     tile_n = full + (rem - tile_m * gw);
   }
@@ -814,7 +835,7 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearA
   auto locate = [&](uint32_t it) {
     Tile t;
     uint32_t tile_m, tile_n;
-    tile_of_block(it, nb, tiles_m, tiles_n, tile_m, tile_n);
+    tile_of_block_gn((uint32_t)p.gn, it, nb, tiles_m, tiles_n, tile_m, tile_n);
     t.m0 = (int64_t)tile_m * BM2;
     t.n0 = (int)tile_n * BN2;
 #pragma unroll
@@ -1290,25 +1311,33 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256_f32x3(const Lin
 constexpr int VM = 128, VN = 256, VROW = 128, VTHREADS = 512, VNST = 3;
 constexpr int VOPER_X = VM * VROW, VOPER_W = VN * VROW, VSTAGE = VOPER_X + VOPER_W;   // 16 + 32 = 48 KiB
 
-template <bool A_PRE, bool W_PRE>   // operand already in the fp16-pair layout: its split (all of its VALU work) disappears
+// A_PRE / W_PRE: operand already in the fp16-pair layout: its split (all of its VALU work) disappears.
+// TALL: the tile is 256 (m) x 128 (n) -- waves 4 x 2, the same 64 x 64 wave tile, the same 48 KiB stage (32 KiB of
+// activations + 16 KiB of weights) and the same six LDS-DMA instructions per lane and stage -- for the narrow linears: the
+// decoder's output heads have 80 real columns (5 variables x 16 pixels), which the 256-wide tile pads to 256 (69 % of
+// its MFMAs on zeros), this one to 128.
+template <bool A_PRE, bool W_PRE, bool TALL = false>
 __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearArgs p_in) {
+  constexpr int TM = TALL ? 256 : VM, TN = TALL ? 128 : VN, OPX = TM * VROW, XP = TM / 64, WP = TN / 64;
+  static_assert(OPX + TN * VROW == VSTAGE && XP + WP == 6, "stage size / DMA count the waitcnt immediates assume");
   const LinearArgs p = batch_problem(p_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.guard != nullptr && !(*p.guard < p.guard_limit)) return;   // guarded launch: the three-term kernel does the work
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;   // waves w and w+4 share a SIMD; wm = 1 runs one phase behind
+  const int late = wave >> 2;   // waves w and w+4 share a SIMD; the late half runs one phase behind
+  const int wm = TALL ? wave >> 1 : wave >> 2, wn = TALL ? wave & 1 : wave & 3;
 
   uint32_t tile_m, tile_n;
   tile_of_block<2>(blockIdx.x, (uint32_t)p.n_blocks, (uint32_t)(p.n_blocks / p.tiles_n), (uint32_t)p.tiles_n, tile_m, tile_n);
-  const int64_t m0 = (int64_t)tile_m * VM;
-  const int n0 = (int)tile_n * VN;
+  const int64_t m0 = (int64_t)tile_m * TM;
+  const int n0 = (int)tile_n * TN;
 
-  const char* src_x[2];
-  const char* src_w[4];
+  const char* src_x[XP];
+  const char* src_w[WP];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < XP; ++r) {
     const int id = r * VTHREADS + tid;
     const int row = id >> 3, c = id & 7;
     int64_t gm = m0 + row;
@@ -1316,7 +1345,7 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
     src_x[r] = p.A + gm * p.lda_b + ((c ^ swz_x(row)) << 4);
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < WP; ++r) {
     const int id = r * VTHREADS + tid;
     const int row = id >> 3, c = id & 7;
     src_w[r] = p.W + (int64_t)(n0 + row) * p.ldw_b + ((c ^ swz_w(row)) << 4);
@@ -1325,13 +1354,13 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
     const int64_t koff = (int64_t)kt * VROW;
     char* base = smem + (kt % VNST) * VSTAGE;
 #pragma unroll
-    for (int r = 0; r < 2; ++r)   // wave-uniform LDS address; the hardware adds lane * 16
+    for (int r = 0; r < XP; ++r)   // wave-uniform LDS address; the hardware adds lane * 16
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[r] + koff),
                                        (lds_ptr_t)(base + (r * VTHREADS + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < WP; ++r)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
-                                       (lds_ptr_t)(base + VOPER_X + (r * VTHREADS + wave * 64) * 16), 16, 0, 0);
+                                       (lds_ptr_t)(base + OPX + (r * VTHREADS + wave * 64) * 16), 16, 0, 0);
   };
   // fragment read offsets.  Lane group g multiplies k = 8g..8g+7 of the stage: as fp32 that is chunks 2g and 2g + 1 of the
   // row, in the fp16-pair layout chunk g (high halves) and chunk g + 4 (remainders) -- the same k order either way, so
@@ -1346,7 +1375,7 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
     for (int ks = 0; ks < 2; ++ks) {
       const int cx = A_PRE ? g + 4 * ks : 2 * g + ks, cw = W_PRE ? g + 4 * ks : 2 * g + ks;
       off_x[f][ks] = row_x * VROW + ((cx ^ swz_x(row_x)) << 4);
-      off_w[f][ks] = VOPER_X + row_w * VROW + ((cw ^ swz_w(row_w)) << 4);
+      off_w[f][ks] = OPX + row_w * VROW + ((cw ^ swz_w(row_w)) << 4);
     }
   }
   f32x4 acc[4][4];  // [fn][fm]
@@ -1362,7 +1391,7 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();   // stage 0 is complete
   asm volatile("" ::: "memory");
-  if (wm == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
+  if (late == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
 
   for (int s = 0; s < nt; ++s) {
     // ---- L(s) ----
@@ -1406,7 +1435,7 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
   }
-  if (wm == 0) __builtin_amdgcn_s_barrier();   // the early half waits for the late half's last phase
+  if (late == 0) __builtin_amdgcn_s_barrier();   // the early half waits for the late half's last phase
   asm volatile("" ::: "memory");
 
   // ---- epilogue: lane owns row m (per fm) x 16 consecutive features; undo the 2^6 weight scale (exact) ----
@@ -1888,8 +1917,8 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
   // pre-split operands / output: the two-term ping-pong kernel only.  An A-split launch cannot fall back to three terms
   // (they need the fp32 values), so it takes no guard; a W-split launch with a guard runs iff the guard holds and the
   // caller pairs it with a mode-1 launch on the fp32 weights carrying the same guard, which runs iff it does not.
-  AURORA_CHECK_ARG(!pre || (dtype == AURORA_F32 && mode == 2 && N % VN == 0 && K % 32 == 0 && K >= 96),
-                   "linear: fp16-pair operands need fp32, mode 2, N %% 256 == 0, K %% 32 == 0, K >= 96 (N=%d K=%d)", N, K);
+  AURORA_CHECK_ARG(!pre || (dtype == AURORA_F32 && mode == 2 && N % 128 == 0 && K % 32 == 0 && K >= 96),
+                   "linear: fp16-pair operands need fp32, mode 2, N %% 128 == 0, K %% 32 == 0, K >= 96 (N=%d K=%d)", N, K);
   // (an A-split launch WITH a guard is for buffers whose format was itself decided by that guard on the device -- written
   // as pairs by a guarded two-term producer iff it holds, as fp32 by its three-term twin otherwise)
   AURORA_CHECK_ARG(!(pre & AURORA_F32_A_SPLIT) || (pre & AURORA_F32_W_SPLIT),
@@ -1913,7 +1942,8 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
   // (fp32 in split mode: the kernel choice must not depend on M, or a latitude band of a sharded model
   // would round differently from the same rows of the un-sharded one.)
   const bool split = dtype == AURORA_F32 && mode >= 1;
-  bool big = (M >= 1024 || split) && N % BN2 == 0;
+  const bool tall = pre != 0 && N % VN != 0;   // pre-split operands, N a multiple of 128 only: the 256 x 128 two-term tiles
+  bool big = (M >= 1024 || split) && (N % BN2 == 0 || tall);
   bool mid = false;   // bf16 only: 256 x 128 tiles of the ring kernel, two 4-wave workgroups per CU
   // split-K on 256 x 256 tiles when the caller brought scratch for it (aurora_hip_linear_ws) and the launch would
   // otherwise leave most of the chip idle
@@ -1971,6 +2001,11 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
 
   p.bs_a = stride_a * es; p.bs_w = stride_w * es; p.bs_c = stride_c * es; p.bs_bias = stride_bias;
   p.split = ksplit; p.slabs = ksplit > 1 ? ws->slabs : nullptr; p.tickets = ksplit > 1 ? ws->tickets : nullptr;
+  {
+    static const int gn_env = [] { const char* e = getenv("AURORA_GEMM_GN"); return e ? atoi(e) : 0; }();   // A/B: 0 = rule
+    static const int gn_k = [] { const char* e = getenv("AURORA_GEMM_GN_K"); return e ? atoi(e) : 1 << 30; }();
+    p.gn = gn_env > 0 && K >= gn_k ? gn_env : 8;
+  }
   dim3 grid((unsigned)p.n_blocks, (unsigned)batch);
   static bool attr_done_dev[64] = {false};   // function attributes are per device
   bool& attr_done = attr_done_dev[current_device() & 63];
@@ -1991,6 +2026,8 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
     (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
     (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
     (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
     attr_done = true;
   }
   // two fp16 terms: the ping-pong kernel (128 x 256 tiles, K-stages of 32) when K allows, else the in-phase 256 x 256 one
@@ -1998,10 +2035,12 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
   auto launch_f32pp = [&]() {
     LinearArgs q = p;
     q.k_tiles = K / 32;
-    q.tiles_n = N / VN;
-    q.n_blocks = ((M + VM - 1) / VM) * q.tiles_n;
+    q.tiles_n = tall ? N / 128 : N / VN;
+    q.n_blocks = tall ? ((M + 255) / 256) * q.tiles_n : ((M + VM - 1) / VM) * q.tiles_n;
     const dim3 g((unsigned)q.n_blocks, (unsigned)batch), b(VTHREADS);
-    if (pre & AURORA_F32_A_SPLIT) hipLaunchKernelGGL((linear_kernel_f32pp<true, true>), g, b, VNST * VSTAGE, as_stream(stream), q);
+    if (tall && (pre & AURORA_F32_A_SPLIT)) hipLaunchKernelGGL((linear_kernel_f32pp<true, true, true>), g, b, VNST * VSTAGE, as_stream(stream), q);
+    else if (tall) hipLaunchKernelGGL((linear_kernel_f32pp<false, true, true>), g, b, VNST * VSTAGE, as_stream(stream), q);
+    else if (pre & AURORA_F32_A_SPLIT) hipLaunchKernelGGL((linear_kernel_f32pp<true, true>), g, b, VNST * VSTAGE, as_stream(stream), q);
     else if (pre & AURORA_F32_W_SPLIT) hipLaunchKernelGGL((linear_kernel_f32pp<false, true>), g, b, VNST * VSTAGE, as_stream(stream), q);
     else hipLaunchKernelGGL((linear_kernel_f32pp<false, false>), g, b, VNST * VSTAGE, as_stream(stream), q);
   };

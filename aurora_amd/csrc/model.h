@@ -126,7 +126,7 @@ struct HeadGroup {
   std::vector<std::string> names;      // head names in column order (variables, then `<v>_mod`)
   DevBuf w, b;                         // [groups][n * P * P][2D], [groups][round_up(n * P * P, 4)]
   int groups = 1;
-  // the same heads for the two-term fp16 GEMM (when the weights allow): rows zero-padded to a multiple of 256 -- the tile
+  // the same heads for the two-term fp16 GEMM (when the weights allow): rows zero-padded to a multiple of 128 -- the narrow tile
   // width of linear_kernel_f32pp --, weights in the fp16-pair layout scaled by 2^6, bias rows padded likewise
   DevBuf ws, bs;                       // [groups][n_pad][2D] pairs, [groups][n_pad]
   int n_pad = 0;                       // 0: not available

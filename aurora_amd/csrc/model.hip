@@ -549,11 +549,11 @@ void build_heads(Model& m, HeadGroup& hg, const char* kind, const std::vector<st
       hip_ok(hipMemcpy(hg.w.f() + ((size_t)g * names.size() + v) * PP * D2, wt.f(), (size_t)PP * D2 * 4, hipMemcpyDeviceToDevice), "copy");
       hip_ok(hipMemcpy(hg.b.f() + (size_t)g * ldb + v * PP, m.W(p + ".bias"), (size_t)PP * 4, hipMemcpyDeviceToDevice), "copy");
     }
-  // ---- the two-term form: N padded to the 256-column tiles of the fp16-pair GEMM (zero rows cost MFMAs, not bytes of A) ----
+  // ---- the two-term form: N padded to whole 128-column tiles of the fp16-pair GEMM (zero rows cost MFMAs, not bytes of A) ----
   hg.n_pad = 0;
   hg.ws = DevBuf(); hg.bs = DevBuf();
   if (std::string(kind) != "atmos" || bounded_mode() != 2 || D2 % 32 != 0 || D2 < 96) return;
-  const int n = (int)names.size() * PP, n_pad = round_up(n, 256);
+  const int n = (int)names.size() * PP, n_pad = round_up(n, 128);   // the tile width of the 256 x 128 two-term kernel
   std::vector<float> hw((size_t)hg.groups * n * D2);
   hip_ok(hipMemcpy(hw.data(), hg.w.p, hw.size() * 4, hipMemcpyDeviceToHost), "download");
   float wmax = 0.f;
@@ -1257,6 +1257,25 @@ extern "C" int aurora_hip_profile_end(aurora_hip_model* m, aurora_hip_profile_en
     }
     m->timed.clear();
     *n_out = K_COUNT;
+  })
+}
+
+extern "C" int aurora_hip_profile_end_list(aurora_hip_model* m, aurora_hip_profile_entry* out, int capacity, int* n_out) {
+  GUARDED({
+    REQUIRE(m && n_out && (out || capacity == 0), "profile_end_list: bad arguments");
+    m->profile_mask = 0;
+    hip_ok(hipDeviceSynchronize(), "profile_end_list");
+    *n_out = (int)m->timed.size();
+    if (capacity < *n_out) return AURORA_OK;   // (query: the launches stay recorded)
+    int i = 0;
+    for (auto& t : m->timed) {
+      float ms = 0.f;
+      hip_ok(hipEventElapsedTime(&ms, t.e0, t.e1), "hipEventElapsedTime");
+      out[i++] = aurora_hip_profile_entry{KIND_NAMES[t.kind], 1, ms, t.work};
+      m->event_pool.push_back(t.e0);
+      m->event_pool.push_back(t.e1);
+    }
+    m->timed.clear();
   })
 }
 

@@ -5,6 +5,8 @@
 // One wavefront owns one row: the row lives in registers (8-element / 16- or 32-byte pieces per
 // lane, lane-interleaved so every load instruction covers a contiguous 1-2 KiB), statistics are
 // two-pass fp32 (mean, then centred second moment) reduced with xor-shuffles.  4 rows per block.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace aurora {
@@ -46,21 +48,33 @@ struct LnArgs {
   int split_res; // fp32 kernel: the residual rows are in that layout (value = high half + remainder)
 };
 
-template <typename T, int NC>   // chunks of 256 features
+// PRE: the residual row is requested together with y (twice the registers; picked for launches with few rows per CU)
+template <typename T, int NC, bool PRE = false>   // chunks of 256 features
 __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= p.M) return;
   const int n_pieces = p.D >> 2;
   const T* yr = reinterpret_cast<const T*>(p.y) + row * p.ldy;
-  float v[NC][4];
-  float s = 0.f;
+  const float* rr = nullptr;
+  if (p.res) rr = p.res + (p.res_mod > 0 ? row % p.res_mod : row) * p.ldr;
+  const bool res_plain = PRE && rr != nullptr && !p.split_res;   // (uniform)
+  float v[NC][4], r4[PRE ? NC : 1][4];
+  // Both operands of a row are requested before anything waits: with few rows per CU (a latitude band's coarse stages:
+  // 2,160 rows on 256 CUs) the kernel is a latency chain, and the residual fetched only after the two reductions made it
+  // two HBM round trips long.
 #pragma unroll
   for (int i = 0; i < NC; ++i)
     if (lane + 64 * i < n_pieces) {
       load4(yr + (lane + 64 * i) * 4, v[i]);
-      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      if constexpr (PRE) {
+        if (res_plain) load4(rr + (lane + 64 * i) * 4, r4[i]);
+      }
     }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+    if (lane + 64 * i < n_pieces) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   const float inv_d = 1.0f / p.D;
   const float mean = wave_sum(s) * inv_d;
   float q = 0.f;
@@ -74,8 +88,6 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
       }
     }
   const float rstd = rsqrtf(wave_sum(q) * inv_d + p.eps);
-  const float* rr = nullptr;
-  if (p.res) rr = p.res + (p.res_mod > 0 ? row % p.res_mod : row) * p.ldr;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int e = (lane + 64 * i) * 4;
@@ -102,10 +114,15 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] += half(hw[j >> 1], j & 1) + half(lw[j >> 1], j & 1);
       } else if (rr) {
-        float r4[4];
-        load4(rr + e, r4);
+        if constexpr (PRE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += r4[j];
+          for (int j = 0; j < 4; ++j) o[j] += r4[i][j];
+        } else {
+          float r[4];
+          load4(rr + e, r);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += r[j];
+        }
       }
       if (p.out_f32) store4(p.out_f32 + row * p.ldo + e, o);
       if (p.out_t && p.split_t) {
@@ -281,11 +298,23 @@ static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const f
     // bf16 rows go through the same 4-features-per-lane kernel: every access of a wave covers whole cache lines (8-byte
     // bf16 pieces, 16-byte fp32 pieces on consecutive lanes; profiles/r02_ab_ln_layout.log)
     const dim3 grid(row_blocks(M)), block(256);
-    if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 1>), grid, block, 0, as_stream(stream), p);
-    else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 2>), grid, block, 0, as_stream(stream), p);
-    else if (D <= 1024) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 4>), grid, block, 0, as_stream(stream), p);
-    else if (D <= 2048) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 8>), grid, block, 0, as_stream(stream), p);
-    else hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 16>), grid, block, 0, as_stream(stream), p);
+    // few rows per CU (a latitude band's stages, the coarse stage of the un-sharded step): the latency chain of a row
+    // bounds the launch, and the variant that requests the residual row up front halves it
+    static const int pre_env = [] { const char* e = getenv("AURORA_LN_PREFETCH"); return e ? atoi(e) : -1; }();
+    const bool pre = res != nullptr && (pre_env >= 0 ? pre_env != 0 : M <= (int64_t)96 * device_cus());
+    if (pre) {
+      if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 1, true>), grid, block, 0, as_stream(stream), p);
+      else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 2, true>), grid, block, 0, as_stream(stream), p);
+      else if (D <= 1024) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 4, true>), grid, block, 0, as_stream(stream), p);
+      else if (D <= 2048) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 8, true>), grid, block, 0, as_stream(stream), p);
+      else hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 16>), grid, block, 0, as_stream(stream), p);
+    } else {
+      if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 1>), grid, block, 0, as_stream(stream), p);
+      else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 2>), grid, block, 0, as_stream(stream), p);
+      else if (D <= 1024) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 4>), grid, block, 0, as_stream(stream), p);
+      else if (D <= 2048) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 8>), grid, block, 0, as_stream(stream), p);
+      else hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 16>), grid, block, 0, as_stream(stream), p);
+    }
   }
   return check_launch("layernorm");
 }

@@ -609,6 +609,7 @@ PROFILE_KINDS = ("linear_bf16", "linear_f32", "window_attention_bf16", "layernor
 _SIGNATURES.update({
     "aurora_hip_profile_begin": (c_int, [c_void_p, ctypes.c_uint32]),
     "aurora_hip_profile_end": (c_int, [c_void_p, ctypes.POINTER(HipProfileEntry), c_int, ctypes.POINTER(c_int)]),
+    "aurora_hip_profile_end_list": (c_int, [c_void_p, ctypes.POINTER(HipProfileEntry), c_int, ctypes.POINTER(c_int)]),
     "aurora_hip_create": (c_int, [ctypes.POINTER(HipConfig), ctypes.POINTER(c_void_p)]),
     "aurora_hip_destroy": (None, [c_void_p]),
     "aurora_hip_pack_weights": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.POINTER(c_int64), c_int, c_int, c_int]),

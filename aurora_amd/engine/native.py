@@ -74,6 +74,11 @@ class _Transport:
         self.error: BaseException | None = None
         self.post_c = lib.HALO_POST_FN(self._post)
         self.wait_c = lib.HALO_WAIT_FN(self._wait)
+        # optional timing of `wait` (bench.py --gpus N): an event pair on the launch stream around every wait, i.e. how long
+        # that stream stood still for messages that had not arrived when the halo projection was due
+        self.time_waits = False
+        self._wait_events: list = []
+        self.exchanges = 0
 
     def allocate(self, n_bytes: int) -> None:
         n = max(int(n_bytes), 16)
@@ -84,6 +89,15 @@ class _Transport:
         try:
             import torch.distributed as dist
 
+            # torch.distributed orders a point-to-point operation against torch's CURRENT stream (ProcessGroupNCCL records its
+            # event there), not against the stream argument of this callback: they must be the same stream, or the gather
+            # kernel that fills `send` is not ordered before the send
+            if self.device != "cpu" and torch.cuda.is_available():
+                cur = torch.cuda.current_stream().cuda_stream
+                if int(stream or 0) != int(cur or 0):
+                    raise RuntimeError(f"halo post on stream {stream}, but torch's current stream is {cur}: run the step "
+                                       "under `torch.cuda.stream(s)` of the stream it launches on")
+            self.exchanges += 1
             sh = self.shard
             to_global = (lambda r: dist.get_global_rank(sh.group, r)) if sh.group is not None else (lambda r: r)
             cut = lambda buf, m: buf[m.offset:m.offset + m.bytes]  # noqa: E731
@@ -109,13 +123,54 @@ class _Transport:
 
     def _wait(self, user, stream) -> int:
         try:
+            timed = self.time_waits and self.works
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for work in self.works:
                 work.wait()   # stream-ordered: the current HIP stream waits, not the host
+            if timed:
+                e1.record()
+                self._wait_events.append((e0, e1))
             self.works = []
             return 0
         except BaseException as e:  # noqa: BLE001
             self.error = e
             return -1
+
+
+    def wait_ms(self) -> float:
+        """Milliseconds the launch stream stood still in `wait` since the last call (synchronises; `time_waits` must be on)."""
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in self._wait_events)
+        self._wait_events = []
+        return ms
+
+    def selftest(self, n_bytes: int = 1 << 20) -> None:
+        """Every rank sends a rank-stamped pattern to its neighbours through this very transport (`_post` / `_wait`, the
+        staging buffers, the process group) and checks what arrived: a mis-wired fabric, rank order or stream order shows
+        up here, before the first step, instead of as a wrong forecast.  Raises on failure."""
+        sh = self.shard
+        if sh is None or sh.world <= 1:
+            return
+        if self.send is None or self.send.numel() < 32:
+            self.allocate(max(2 * n_bytes, 32))
+        n = min(n_bytes, self.send.numel() // 2) // 16 * 16
+        peers = [p for p in (sh.rank - 1, sh.rank + 1) if 0 <= p < sh.world]
+        idx = torch.arange(n, device=self.device, dtype=torch.int64)
+        msgs = (lib.HipHaloMsg * 2)()
+        for i, peer in enumerate(peers):
+            self.send[i * n:(i + 1) * n] = ((sh.rank * 31 + peer * 7 + idx) % 251).to(torch.uint8)
+            msgs[i].peer, msgs[i].reserved, msgs[i].offset, msgs[i].bytes = peer, 0, i * n, n
+        self.recv[:len(peers) * n] = 0xEE
+        stream = lib._stream() if self.device != "cpu" else 0
+        if self._post(None, msgs, len(peers), msgs, len(peers), stream) != 0 or self._wait(None, stream) != 0:
+            raise RuntimeError(f"halo transport self-test failed on rank {sh.rank}") from self.error
+        for i, peer in enumerate(peers):
+            want = ((peer * 31 + sh.rank * 7 + idx) % 251).to(torch.uint8)
+            if not torch.equal(self.recv[i * n:(i + 1) * n], want):
+                bad = int((self.recv[i * n:(i + 1) * n] != want).nonzero()[0])
+                raise RuntimeError(f"halo transport self-test: rank {sh.rank} received a wrong byte {bad} from rank {peer}")
 
 
 class NativeModel:
@@ -271,6 +326,14 @@ class NativeModel:
         n = ctypes.c_int(0)
         lib._check(lib.load().aurora_hip_profile_end(self._h, out, len(out), ctypes.byref(n)))
         return {e.kernel.decode(): {"launches": e.launches, "ms": e.ms, "work": e.work} for e in out[:n.value] if e.launches}
+
+    def profile_end_list(self) -> list:
+        """[(kernel, ms, work)] per launch, in launch order (synchronises the device)."""
+        n = ctypes.c_int(0)
+        lib._check(lib.load().aurora_hip_profile_end_list(self._h, None, 0, ctypes.byref(n)))
+        out = (lib.HipProfileEntry * max(n.value, 1))()
+        lib._check(lib.load().aurora_hip_profile_end_list(self._h, out, n.value, ctypes.byref(n)))
+        return [(e.kernel.decode(), e.ms, e.work) for e in out[:n.value]]
 
     def set_time(self, times) -> None:
         """Clock-dependent inputs: the absolute-time encoding (encoder.py:359-363) and the calendar fields of the dynamic

@@ -292,7 +292,13 @@ def main() -> None:
         backend = os.environ.get("AURORA_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(local_rank)
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend, timeout=timedelta(seconds=600), **kw)
+        try:
+            dist.init_process_group(backend, timeout=timedelta(seconds=600), **kw)
+        except Exception as e:  # noqa: BLE001  -- one JSON line the driver can record instead of N tracebacks
+            if rank == 0:
+                print(json.dumps({"metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13", "value": None,
+                                  "n_gpus": world, "error": f"process-group initialisation ({backend}) failed: {e!r}"}), flush=True)
+            raise SystemExit(3)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -307,6 +313,16 @@ def main() -> None:
         full = synthetic_batch(model.config, GH, GW, 1, device)
         batch = model.engine().local_band(full.crop(model.patch_size))
         del full
+        # before anything is timed: every rank sends a stamped pattern of a real halo message's size to its neighbours
+        # through the production transport and checks what arrived (a wrong rank order / fabric / stream order fails here)
+        transport = model.engine().native.transport
+        try:
+            transport.selftest(4 << 20)
+        except Exception as e:  # noqa: BLE001
+            print(json.dumps({"metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13", "value": None, "n_gpus": world,
+                              "rank": rank, "error": f"halo transport self-test failed: {e!r}"}), flush=True)
+            raise SystemExit(4)
+        log("halo transport self-test ok")
     else:
         batch = synthetic_batch(model.config, GH, GW, 1 + (rank if mode == "replicas" else 0), device)
     log("batch on device")
@@ -341,6 +357,26 @@ def main() -> None:
         eng.profile_start()          # (3) one more step with events around everything, for the per-kernel breakdown
         model.forward(batch)
         breakdown = eng.profile_stop()
+        # (4) sharded runs: K more steps per rank with an event pair around every halo `wait` on the launch stream -- how
+        # long a rank's stream stood still for messages (what the exchange did NOT hide) -- next to the rank's own step time
+        # measured WITHOUT a barrier between ranks; the first scaling record then says whether a rank is slow or waiting
+        per_rank = None
+        if mode == "bands":
+            tr = eng.native.transport
+            tr.time_waits = True
+            tr.wait_ms()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                model.forward(batch)
+            torch.cuda.synchronize()
+            mine = [(time.perf_counter() - t1) / args.steps * 1e3, tr.wait_ms() / args.steps, float(tr.exchanges)]
+            tr.time_waits = False
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            per_rank = {"step_ms": [round(v[0], 3) for v in every], "halo_wait_ms": [round(v[1], 3) for v in every],
+                        "compute_ms": [round(v[0] - v[1], 3) for v in every],
+                        "max_rank_compute_ms": round(max(v[0] - v[1] for v in every), 3)}
     assert torch.isfinite(pred.surf_vars["2t"]).all()
 
     if distributed:
@@ -364,15 +400,24 @@ def main() -> None:
         # `traffic_build` names the commit whose library those passes profiled.
         traffic, traffic_build = None, None
         pmc = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))
+        traffic_stale = None
         if pmc:
+            import hashlib
+
             pj = json.loads(pmc[-1].read_text())
             traffic, traffic_build = pj.get("linear_bf16_hbm_bytes_per_launch"), pj.get("build_commit")
+            # counters are static evidence of the build they profiled: if the GEMM source has changed since (its SHA-256 is
+            # recorded by tools/pmc_rollup.py), the figure is withheld instead of going stale silently
+            sha = hashlib.sha256((ROOT / "aurora_amd" / "csrc" / "gemm.hip").read_bytes()).hexdigest()
+            traffic_stale = pj.get("gemm_source_sha256") != sha
+            if traffic_stale:
+                traffic = None
         per = max(args.steps, 1)
         out = {
             "metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13",
             "value": value, "unit": "forecast-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if mode == "bands" else "weak", "vs_baseline": None, "dtype": "bf16",
+            "scaling": "strong" if mode == "bands" else "weak" if mode == "replicas" else "n/a", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": f"AuroraPretrained(autocast=True) 1.3B, 0.25deg ERA5 {GH}x{GW}, 13 levels, "
                                    "T=2, batch 1 per GPU, one forward step (BASELINE.json configs[1])",
@@ -389,7 +434,7 @@ def main() -> None:
                 "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_source": f"profiles/{pmc[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command; "
                                   "2 x FETCH_SIZE per profiles/r02_fetch_calibration.txt)" if pmc else None,
-                "traffic_build": traffic_build,
+                "traffic_build": traffic_build, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_GEMM_LAUNCH,
                 "launches_per_step": g["launches"] / per, "ms_per_step": g["ms"] / per,
                 "frac_all_matrix_launches": all_tf / PEAK_BF16_TFLOPS,
@@ -402,6 +447,11 @@ def main() -> None:
             "step_tflops": FLOP_PER_STEP / (ms_per_step * 1e-3) / 1e12 if (GH, GW) == (721, 1440) else None,
             "kernel_ms_per_step": {k: v["ms"] for k, v in sorted(breakdown.items())},   # (the extra, un-timed step)
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        # the GPU measurement is safe in the log before the (long) CPU leg starts: a driver that gives up on the CPU oracle
+        # still finds it on stderr; stdout carries exactly one line, at the end
+        log("GPU-only result: " + json.dumps(out))
         if world == 1 and not args.no_cpu_baseline:
             log("running the CPU oracle on the same weights and Batch (full grid)")
             out["cpu_baseline"], oracle_out = cpu_baseline(model, GH, GW, args.cpu_budget)

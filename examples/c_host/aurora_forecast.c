@@ -6,6 +6,12 @@
  * file (aurora_hip_save_packed; no pickle, no checkpoint adapters on this side).
  *
  *   aurora_forecast <case-dir>
+ *   aurora_forecast <case-dir> --rank R --world N --nccl-id FILE [--device D]      (built with -DAURORA_WITH_RCCL)
+ *
+ * The second form runs ONE latitude band of the forecast: N processes, one per GPU, started by any
+ * launcher (a shell loop will do); rank 0 writes RCCL's unique id to FILE, the others read it; the halo rows of the
+ * shifted-window blocks travel over RCCL point-to-point (examples/c_host/rccl_transport.c).  Every rank reads its own rows
+ * of the input files and writes pred<step>_..._rank<R>.f32 with its rows of the prediction.
  *
  * <case-dir>/case.txt     whitespace-separated `key value...` records (see read_case below): the Aurora.__init__ keywords
  *                          of the ERA5 model family, the grid, the normalisation statistics, B, T, steps, time stamps
@@ -18,6 +24,7 @@
  * Build (tests/test_c_host.py does exactly this):
  *   gcc -std=c99 -O1 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_host/aurora_forecast.c \
  *       -o aurora_forecast -Laurora_amd/_lib -laurora_hip -L/opt/rocm/lib -lamdhip64 -lm
+ *   (band mode: add -DAURORA_WITH_RCCL -D_POSIX_C_SOURCE=200809L examples/c_host/rccl_transport.c -lrccl)
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -26,6 +33,9 @@
 #include <string.h>
 
 #include "aurora_hip.h"
+#ifdef AURORA_WITH_RCCL
+#include "rccl_transport.h"
+#endif
 
 #define MAX_VARS 32
 #define MAX_DIM 8192
@@ -127,8 +137,8 @@ static void read_case(const char* dir, forecast_case* c) {
   g->atmos_vars = (const char* const*)c->atmos.v;
 }
 
-/* Reads `planes` images of (n_lat, n_lon) and uploads their first `rows` latitude rows, packed. */
-static float* upload_cropped(const char* dir, const char* kind, const char* var, int64_t planes, int n_lat, int rows, int n_lon) {
+/* Reads `planes` images of (n_lat, n_lon) and uploads their latitude rows [row0, row0 + rows), packed. */
+static float* upload_rows(const char* dir, const char* kind, const char* var, int64_t planes, int n_lat, int row0, int rows, int n_lon) {
   char path[4096];
   snprintf(path, sizeof path, "%s/%s_%s.f32", dir, kind, var);
   FILE* f = fopen(path, "rb");
@@ -139,16 +149,17 @@ static float* upload_cropped(const char* dir, const char* kind, const char* var,
   HIP(hipMalloc((void**)&dev, sizeof(float) * kept * planes));
   for (int64_t p = 0; p < planes; ++p) {
     if (fread(host, sizeof(float), image, f) != image) die("short file", path);
-    HIP(hipMemcpy(dev + p * kept, host, sizeof(float) * kept, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(dev + p * kept, host + (size_t)row0 * n_lon, sizeof(float) * kept, hipMemcpyHostToDevice));
   }
   free(host);
   fclose(f);
   return dev;
 }
 
-static void download(const char* dir, int step, const char* kind, const char* var, const float* dev, size_t n) {
+static void download(const char* dir, int step, const char* kind, const char* var, int rank, const float* dev, size_t n) {
   char path[4096];
-  snprintf(path, sizeof path, "%s/pred%d_%s_%s.f32", dir, step, kind, var);
+  if (rank < 0) snprintf(path, sizeof path, "%s/pred%d_%s_%s.f32", dir, step, kind, var);
+  else snprintf(path, sizeof path, "%s/pred%d_%s_%s_rank%d.f32", dir, step, kind, var, rank);
   float* host = (float*)malloc(sizeof(float) * n);
   HIP(hipMemcpy(host, dev, sizeof(float) * n, hipMemcpyDeviceToHost));
   FILE* f = fopen(path, "wb");
@@ -169,10 +180,27 @@ static void push_history(float* hist, const float* pred, int B, int T, size_t pl
 }
 
 int main(int argc, char** argv) {
-  if (argc != 2) {
-    fprintf(stderr, "usage: aurora_forecast <case-dir>   (library ABI version %d)\n", aurora_hip_version());
+  int rank = -1, world = 1, device = -1;
+  const char* id_file = NULL;
+  int bad = argc < 2;
+  for (int i = 2; i < argc && !bad; i += 2) {
+    if (i + 1 >= argc) bad = 1;
+    else if (!strcmp(argv[i], "--rank")) rank = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--world")) world = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--device")) device = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--nccl-id")) id_file = argv[i + 1];
+    else bad = 1;
+  }
+  if (world > 1 && (rank < 0 || rank >= world || !id_file)) bad = 1;
+  if (bad) {
+    fprintf(stderr, "usage: aurora_forecast <case-dir> [--rank R --world N --nccl-id FILE [--device D]]   (library ABI version %d)\n",
+            aurora_hip_version());
     return 2;
   }
+#ifndef AURORA_WITH_RCCL
+  if (world > 1) die("band mode", "this binary was built without -DAURORA_WITH_RCCL");
+#endif
+  if (world <= 1) rank = -1;
   const char* dir = argv[1];
   static forecast_case c;
   read_case(dir, &c);
@@ -181,7 +209,7 @@ int main(int argc, char** argv) {
       sizes[1] != (int32_t)sizeof(aurora_hip_grid) || sizes[2] != (int32_t)sizeof(aurora_hip_step_io))
     die("ABI", "struct sizes of this build differ from the library's");
 
-  HIP(hipSetDevice(0));
+  HIP(hipSetDevice(device >= 0 ? device : (rank > 0 ? rank : 0)));
   hipStream_t stream;
   HIP(hipStreamCreate(&stream));
 
@@ -191,6 +219,16 @@ int main(int argc, char** argv) {
   AUR(aurora_hip_create(&c.cfg, &model));
   AUR(aurora_hip_load_packed(model, path));
   AUR(aurora_hip_finalize(model, stream));
+#ifdef AURORA_WITH_RCCL
+  static rccl_transport transport;
+  if (world > 1) {   /* call order of include/aurora_hip.h: set_band, precompute with the FULL grid, band_rows, staging */
+    if (rccl_transport_init(&transport, rank, world, id_file, 120.0) != 0) die("RCCL", transport.error);
+    aurora_hip_band band;
+    band.rank = rank, band.world = world;
+    band.post = rccl_transport_post, band.wait = rccl_transport_wait, band.user = &transport;
+    AUR(aurora_hip_set_band(model, &band));
+  }
+#endif
 
   /* Batch.crop: a grid with one latitude row more than a multiple of the patch size loses its last row */
   const int P = c.cfg.patch_size, H = c.n_lat - (c.n_lat % P == 1 ? 1 : 0), W = c.n_lon, C = c.n_levels, B = c.B, T = c.T;
@@ -202,16 +240,29 @@ int main(int argc, char** argv) {
   grid.static_loc = c.static_loc, grid.static_scale = c.static_scale;
   grid.atmos_loc = c.atmos_loc, grid.atmos_scale = c.atmos_scale;
   AUR(aurora_hip_precompute(model, &grid, stream));
+  int row0 = 0, Hb = H;   /* this process's latitude rows: the whole (cropped) grid, or its band */
+#ifdef AURORA_WITH_RCCL
+  if (world > 1) {
+    int32_t r0 = 0, r1 = 0;
+    AUR(aurora_hip_band_rows(model, &r0, &r1));
+    row0 = r0, Hb = r1 - r0;
+    if (rccl_transport_allocate(&transport, aurora_hip_band_staging_bytes(model)) != 0) die("RCCL", transport.error);
+    AUR(aurora_hip_set_band_staging(model, transport.send, transport.recv, transport.staging_bytes));
+    if (rccl_transport_selftest(&transport, 1 << 20, stream) != 0) die("RCCL self-test", transport.error);
+    fprintf(stderr, "aurora_forecast: rank %d of %d owns latitude rows [%d, %d), halo staging %.1f MiB, transport self-test ok\n",
+            rank, world, row0, row0 + Hb, (double)transport.staging_bytes / 1048576.0);
+  }
+#endif
 
-  const size_t plane = (size_t)H * W;
+  const size_t plane = (size_t)Hb * W;
   float *surf[MAX_VARS], *stat[MAX_VARS], *atmos[MAX_VARS], *out_surf[MAX_VARS], *out_atmos[MAX_VARS];
   for (int i = 0; i < c.surf.n; ++i) {
-    surf[i] = upload_cropped(dir, "surf", c.surf.v[i], (int64_t)B * T, c.n_lat, H, W);
+    surf[i] = upload_rows(dir, "surf", c.surf.v[i], (int64_t)B * T, c.n_lat, row0, Hb, W);
     HIP(hipMalloc((void**)&out_surf[i], sizeof(float) * B * plane));
   }
-  for (int i = 0; i < c.stat.n; ++i) stat[i] = upload_cropped(dir, "static", c.stat.v[i], 1, c.n_lat, H, W);
+  for (int i = 0; i < c.stat.n; ++i) stat[i] = upload_rows(dir, "static", c.stat.v[i], 1, c.n_lat, row0, Hb, W);
   for (int i = 0; i < c.atmos.n; ++i) {
-    atmos[i] = upload_cropped(dir, "atmos", c.atmos.v[i], (int64_t)B * T * C, c.n_lat, H, W);
+    atmos[i] = upload_rows(dir, "atmos", c.atmos.v[i], (int64_t)B * T * C, c.n_lat, row0, Hb, W);
     HIP(hipMalloc((void**)&out_atmos[i], sizeof(float) * B * C * plane));
   }
 
@@ -232,15 +283,23 @@ int main(int argc, char** argv) {
     AUR(aurora_hip_set_time(model, hours, B, stream));
     AUR(aurora_hip_step(model, &io, stream));
     HIP(hipStreamSynchronize(stream));
-    for (int i = 0; i < c.surf.n; ++i) download(dir, step, "surf", c.surf.v[i], out_surf[i], (size_t)B * plane);
-    for (int i = 0; i < c.atmos.n; ++i) download(dir, step, "atmos", c.atmos.v[i], out_atmos[i], (size_t)B * C * plane);
+    for (int i = 0; i < c.surf.n; ++i) download(dir, step, "surf", c.surf.v[i], rank, out_surf[i], (size_t)B * plane);
+    for (int i = 0; i < c.atmos.n; ++i) download(dir, step, "atmos", c.atmos.v[i], rank, out_atmos[i], (size_t)B * C * plane);
     for (int i = 0; i < c.surf.n; ++i) push_history(surf[i], out_surf[i], B, T, plane, stream);
     for (int i = 0; i < c.atmos.n; ++i) push_history(atmos[i], out_atmos[i], B, T, (size_t)C * plane, stream);
     for (int b = 0; b < B; ++b) hours[b] += c.cfg.timestep_hours;
   }
   HIP(hipStreamSynchronize(stream));
-  printf("aurora_forecast: %d step(s) of a %d x %d x %d grid, workspace %.1f MiB\n", c.steps, C, H, W,
+  printf("aurora_forecast: %d step(s) of a %d x %d x %d grid, workspace %.1f MiB\n", c.steps, C, Hb, W,
          (double)aurora_hip_workspace_bytes(model) / 1048576.0);
+#ifdef AURORA_WITH_RCCL
+  if (world > 1) {
+    printf("aurora_forecast: rank %d: %lld halo exchanges, %.1f MiB sent\n", rank, (long long)transport.exchanges,
+           (double)transport.bytes_sent / 1048576.0);
+    aurora_hip_set_band(model, NULL);
+    rccl_transport_destroy(&transport);
+  }
+#endif
   aurora_hip_destroy(model);
   HIP(hipStreamDestroy(stream));
   return 0;

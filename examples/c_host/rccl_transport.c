@@ -1,0 +1,148 @@
+/* See rccl_transport.h.  C99 + the HIP runtime's C API + RCCL's C API. */
+#include "rccl_transport.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define T_FAIL(t, ...)                                   \
+  do {                                                   \
+    snprintf((t)->error, sizeof (t)->error, __VA_ARGS__); \
+    return -1;                                           \
+  } while (0)
+#define T_HIP(t, call)                                                         \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) T_FAIL(t, "%s: %s", #call, hipGetErrorString(e_));   \
+  } while (0)
+#define T_NCCL(t, call)                                                        \
+  do {                                                                         \
+    ncclResult_t r_ = (call);                                                  \
+    if (r_ != ncclSuccess) T_FAIL(t, "%s: %s", #call, ncclGetErrorString(r_)); \
+  } while (0)
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int rccl_transport_init(rccl_transport* t, int rank, int world, const char* id_file, double timeout_s) {
+  memset(t, 0, sizeof *t);
+  t->rank = rank, t->world = world;
+  if (world < 2 || rank < 0 || rank >= world) T_FAIL(t, "bad rank %d of %d", rank, world);
+  ncclUniqueId id;
+  if (rank == 0) {
+    T_NCCL(t, ncclGetUniqueId(&id));
+    char tmp[4096];
+    snprintf(tmp, sizeof tmp, "%s.tmp", id_file);
+    FILE* f = fopen(tmp, "wb");
+    if (!f || fwrite(&id, sizeof id, 1, f) != 1) T_FAIL(t, "cannot write %.200s", tmp);
+    fclose(f);
+    if (rename(tmp, id_file) != 0) T_FAIL(t, "cannot rename %.200s", tmp);
+  } else {
+    const double t0 = now_s();
+    for (;;) {
+      FILE* f = fopen(id_file, "rb");
+      if (f) {
+        const size_t n = fread(&id, sizeof id, 1, f);
+        fclose(f);
+        if (n == 1) break;
+      }
+      if (now_s() - t0 > timeout_s) T_FAIL(t, "no ncclUniqueId in %.180s after %.0f s", id_file, timeout_s);
+      struct timespec nap = {0, 20 * 1000 * 1000};
+      nanosleep(&nap, NULL);
+    }
+  }
+  T_NCCL(t, ncclCommInitRank(&t->comm, world, id, rank));
+  T_HIP(t, hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+  T_HIP(t, hipEventCreateWithFlags(&t->ready, hipEventDisableTiming));
+  T_HIP(t, hipEventCreateWithFlags(&t->done, hipEventDisableTiming));
+  return 0;
+}
+
+int rccl_transport_allocate(rccl_transport* t, int64_t staging_bytes) {
+  if (staging_bytes < 16) staging_bytes = 16;
+  T_HIP(t, hipMalloc((void**)&t->send, (size_t)staging_bytes));
+  T_HIP(t, hipMalloc((void**)&t->recv, (size_t)staging_bytes));
+  t->staging_bytes = staging_bytes;
+  return 0;
+}
+
+int rccl_transport_post(void* user, const aurora_hip_halo_msg* sends, int32_t n_sends, const aurora_hip_halo_msg* recvs,
+                        int32_t n_recvs, void* stream) {
+  rccl_transport* t = (rccl_transport*)user;
+  for (int i = 0; i < n_sends; ++i)
+    if (sends[i].offset < 0 || sends[i].offset + sends[i].bytes > t->staging_bytes || abs(sends[i].peer - t->rank) != 1)
+      T_FAIL(t, "bad send message %d (peer %d, %lld + %lld bytes)", i, sends[i].peer, (long long)sends[i].offset, (long long)sends[i].bytes);
+  for (int i = 0; i < n_recvs; ++i)
+    if (recvs[i].offset < 0 || recvs[i].offset + recvs[i].bytes > t->staging_bytes || abs(recvs[i].peer - t->rank) != 1)
+      T_FAIL(t, "bad receive message %d (peer %d, %lld + %lld bytes)", i, recvs[i].peer, (long long)recvs[i].offset, (long long)recvs[i].bytes);
+  T_HIP(t, hipEventRecord(t->ready, (hipStream_t)stream));
+  T_HIP(t, hipStreamWaitEvent(t->side, t->ready, 0));
+  T_NCCL(t, ncclGroupStart());
+  for (int i = 0; i < n_sends; ++i) {
+    T_NCCL(t, ncclSend(t->send + sends[i].offset, (size_t)sends[i].bytes, ncclUint8, sends[i].peer, t->comm, t->side));
+    t->bytes_sent += sends[i].bytes;
+  }
+  for (int i = 0; i < n_recvs; ++i)
+    T_NCCL(t, ncclRecv(t->recv + recvs[i].offset, (size_t)recvs[i].bytes, ncclUint8, recvs[i].peer, t->comm, t->side));
+  T_NCCL(t, ncclGroupEnd());
+  T_HIP(t, hipEventRecord(t->done, t->side));
+  t->exchanges += 1;
+  return 0;
+}
+
+int rccl_transport_wait(void* user, void* stream) {
+  rccl_transport* t = (rccl_transport*)user;
+  T_HIP(t, hipStreamWaitEvent((hipStream_t)stream, t->done, 0));
+  return 0;
+}
+
+int rccl_transport_selftest(rccl_transport* t, int64_t bytes, hipStream_t stream) {
+  if (bytes > t->staging_bytes / 2) bytes = t->staging_bytes / 2;
+  bytes &= ~(int64_t)15;
+  if (bytes <= 0) return 0;
+  /* send buffer: [to previous | to next], byte i of the message for peer p = (rank * 31 + p * 7 + i) mod 251 */
+  unsigned char* host = (unsigned char*)malloc((size_t)(2 * bytes));
+  aurora_hip_halo_msg sends[2], recvs[2];
+  int ns = 0;
+  for (int side = 0; side < 2; ++side) {
+    const int peer = side == 0 ? t->rank - 1 : t->rank + 1;
+    if (peer < 0 || peer >= t->world) continue;
+    for (int64_t i = 0; i < bytes; ++i) host[ns * bytes + i] = (unsigned char)((t->rank * 31 + peer * 7 + i) % 251);
+    sends[ns].peer = recvs[ns].peer = peer;
+    sends[ns].reserved = recvs[ns].reserved = 0;
+    sends[ns].offset = recvs[ns].offset = ns * bytes;
+    sends[ns].bytes = recvs[ns].bytes = bytes;
+    ++ns;
+  }
+  T_HIP(t, hipMemcpyAsync(t->send, host, (size_t)(ns * bytes), hipMemcpyHostToDevice, stream));
+  T_HIP(t, hipMemsetAsync(t->recv, 0xee, (size_t)(ns * bytes), stream));
+  if (rccl_transport_post(t, sends, ns, recvs, ns, stream) != 0 || rccl_transport_wait(t, stream) != 0) {
+    free(host);
+    return -1;
+  }
+  T_HIP(t, hipMemcpyAsync(host, t->recv, (size_t)(ns * bytes), hipMemcpyDeviceToHost, stream));
+  T_HIP(t, hipStreamSynchronize(stream));
+  for (int m = 0; m < ns; ++m)
+    for (int64_t i = 0; i < bytes; ++i)
+      if (host[m * bytes + i] != (unsigned char)((recvs[m].peer * 31 + t->rank * 7 + i) % 251)) {
+        const int got = host[m * bytes + i];
+        free(host);
+        T_FAIL(t, "self-test: byte %lld of the message from rank %d is %d", (long long)i, recvs[m].peer, got);
+      }
+  free(host);
+  return 0;
+}
+
+void rccl_transport_destroy(rccl_transport* t) {
+  if (t->send) (void)hipFree(t->send);
+  if (t->recv) (void)hipFree(t->recv);
+  if (t->ready) (void)hipEventDestroy(t->ready);
+  if (t->done) (void)hipEventDestroy(t->done);
+  if (t->side) (void)hipStreamDestroy(t->side);
+  if (t->comm) (void)ncclCommDestroy(t->comm);
+  memset(t, 0, sizeof *t);
+}

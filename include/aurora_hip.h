@@ -536,6 +536,9 @@ typedef struct aurora_hip_profile_entry {
 } aurora_hip_profile_entry;
 int aurora_hip_profile_begin(aurora_hip_model* model, uint32_t kind_mask);
 int aurora_hip_profile_end(aurora_hip_model* model, aurora_hip_profile_entry* out, int capacity, int* n_out);
+/* The same, one entry per LAUNCH in launch order (launches = 1; `work` tells the shapes of a kind apart).  With capacity
+ * smaller than the number of recorded launches only *n_out is set and the recording is kept: query first, then fetch. */
+int aurora_hip_profile_end_list(aurora_hip_model* model, aurora_hip_profile_entry* out, int capacity, int* n_out);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ def test_bench_line_with_oracle_parity_on_a_reduced_grid():
     """The default single-GPU run, on 181 x 360: one JSON line carrying roofline (plain and all-launch fractions),
     cpu_baseline from the oracle on the same weights / Batch, and the parity of the two."""
     d = _run(["--grid", "181x360", "--steps", "2", "--warmup", "1", "--cpu-budget", "600"])
-    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "n/a"
     r = d["roofline"]
     assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and 0 < r["frac_all_matrix_launches"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["full_grid"] is True
@@ -54,3 +54,8 @@ def test_bench_gpus_2_launches_its_own_ranks():
     d = _run(["--gpus", "2", "--grid", "181x360", "--steps", "2", "--warmup", "1"],
              env={"AURORA_BENCH_SAME_GPU": "1", "AURORA_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    # the transport self-test ran (the run would have ended with an `error` line otherwise), and the record explains itself:
+    # per rank, the step time without a barrier and the time the launch stream stood still in the halo `wait`s
+    pr = d["per_rank"]
+    assert len(pr["step_ms"]) == len(pr["halo_wait_ms"]) == len(pr["compute_ms"]) == 2
+    assert all(w >= 0 for w in pr["halo_wait_ms"]) and pr["max_rank_compute_ms"] == max(pr["compute_ms"]) > 0

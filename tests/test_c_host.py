@@ -21,11 +21,14 @@ LIBDIR = ROOT / "aurora_amd" / "_lib"
 _MODES = {"single": 0, "from_second": 1, "all": 2}
 
 
-def build_host(out_dir: Path) -> Path:
-    exe = out_dir / "aurora_forecast"
+def build_host(out_dir: Path, rccl: bool = False) -> Path:
+    """`rccl`: the band mode too -- the halo transport over librccl (examples/c_host/rccl_transport.c)."""
+    exe = out_dir / ("aurora_forecast_rccl" if rccl else "aurora_forecast")
+    extra_src = [str(SRC.parent / "rccl_transport.c")] if rccl else []
+    extra = ["-DAURORA_WITH_RCCL", "-D_POSIX_C_SOURCE=200809L", f"-I{SRC.parent}"] if rccl else []
     cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'include'}",
-           str(SRC), "-o", str(exe), f"-L{LIBDIR}", "-laurora_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
-           f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"]
+           *extra, str(SRC), *extra_src, "-o", str(exe), f"-L{LIBDIR}", "-laurora_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           *(["-lrccl"] if rccl else []), "-lm", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
     return exe
@@ -35,6 +38,20 @@ def test_c_host_example_builds_and_links(tmp_path):
     exe = build_host(tmp_path)
     res = subprocess.run([str(exe)], capture_output=True, text=True)     # no arguments: usage + the library's ABI version
     assert res.returncode == 2 and "usage: aurora_forecast" in res.stderr and "ABI version" in res.stderr
+
+
+def test_c_host_band_mode_builds_and_links_against_rccl(tmp_path):
+    """A latitude band with no Python in the process: the C host with the RCCL transport (ncclSend / ncclRecv in one
+    ncclGroup per exchange on a side stream, events to and from the launch stream) compiles warning-free and links against
+    librccl and every band entry point of the library it uses.  It cannot RUN here or on the one-GPU box (RCCL refuses two
+    ranks on one device): the self-test it performs before its first step is what a multi-GPU host would see first."""
+    exe = build_host(tmp_path, rccl=True)
+    for args in ([], [str(tmp_path), "--world", "2"], [str(tmp_path), "--rank", "2", "--world", "2", "--nccl-id", "x"]):
+        res = subprocess.run([str(exe), *args], capture_output=True, text=True)
+        assert res.returncode == 2 and "--nccl-id FILE" in res.stderr, (args, res.stderr)
+    plain = build_host(tmp_path)
+    res = subprocess.run([str(plain), str(tmp_path), "--rank", "0", "--world", "2", "--nccl-id", "x"], capture_output=True, text=True)
+    assert res.returncode == 1 and "without -DAURORA_WITH_RCCL" in res.stderr
 
 
 def write_case(path: Path, case, cfg, surf, static, atmos, lat, lon, times) -> None:

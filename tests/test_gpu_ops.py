@@ -185,6 +185,29 @@ def test_linear_fp32_presplit_operands_are_bit_identical(M, N, K, act):
         L.linear(a_s, w, b, out, presplit=L.F32_A_SPLIT)             # pre-split activations need pre-split weights
 
 
+@pytest.mark.parametrize("M,N,K", [(1030, 128, 96), (5000, 384, 1024), (70000, 128, 1024)])
+def test_linear_fp32_narrow_two_term_tiles_equal_the_wide_ones(M, N, K):
+    """The 256 x 128 tiling of the two-term kernel (N a multiple of 128 only: the decoder's output heads, 80 real columns)
+    multiplies in the same K order as the 128 x 256 one: bit-identical to it on weights zero-padded to 256 columns."""
+    L = lib()
+    a = rnd(M, K, seed=1).float().to(DEV)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).float().to(DEV)
+    b = rnd(N, seed=3).float().to(DEV)
+    Np = (N + 255) // 256 * 256
+    wp, bp = torch.zeros((Np, K), device=DEV), torch.zeros(Np, device=DEV)
+    wp[:N], bp[:N] = w, b
+    ws, wps, a_s = L.split_f16(w, scale=64.0), L.split_f16(wp, scale=64.0), L.split_f16(a)
+    wide = torch.empty((M, Np), device=DEV)
+    L.linear(a_s, wps, bp, wide, presplit=L.F32_W_SPLIT | L.F32_A_SPLIT)
+    for flags, a_in in ((L.F32_W_SPLIT, a), (L.F32_W_SPLIT | L.F32_A_SPLIT, a_s)):
+        out = torch.full((M, N), float("nan"), device=DEV)
+        L.linear(a_in, ws, b, out, presplit=flags)
+        torch.cuda.synchronize()
+        assert torch.equal(out, wide[:, :N]), flags
+    ref = a.double().cpu() @ w.double().cpu().T + b.double().cpu()
+    assert relerr(out, ref) < 2e-6
+
+
 @pytest.mark.parametrize("amax", [3.0, 1.0e6])
 def test_linear_fp32_presplit_weights_guarded_pair(amax):
     """Pre-split weights with a guard: the two-term launch runs iff the guard holds, a mode-1 launch with the same guard
@@ -321,6 +344,44 @@ def test_linear_bf16(M, N, K, act):
     # fp32 copy: exact products, fp32 accumulation; the bf16 kernel's GELU uses a 4e-7-accurate erf
     assert relerr(out2, ref) < (5e-6 if act == 0 else 2e-5)
     assert relerr(out.float(), ref) < 5e-3    # bf16 copy: one rounding
+
+
+@pytest.mark.parametrize("M,N,K,split", [(2160, 2048, 8192, 0), (2160, 2048, 8192, 2), (2160, 2048, 8192, 3), (2160, 2048, 8192, 5),
+                                           (1100, 512, 4096, 4), (4320, 1024, 4096, 2)])
+@pytest.mark.parametrize("epilogue", ["plain", "dual"])
+def test_linear_ws_split_k_equals_the_unsplit_product(M, N, K, split, epilogue):
+    """Split-K inside one launch (aurora_hip_linear_ws: a latitude band's few-tile / long-K linears): the fp32 copy of the
+    result equals the fp64 product like the un-split kernel's, the bf16 copy differs from the un-split kernel's by at most
+    one rounding (the slices are added in fp32 before the one rounding to bf16), the result does not depend on which
+    workgroup came last (two runs: bit-identical), and the tickets are left zero for the next launch."""
+    L = lib()
+    a = rnd(M, K, seed=1).bfloat16()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16()
+    b = rnd(N, seed=3)
+    ref = a.double() @ w.double().T + b
+    ad, wd, bd = a.to(DEV), w.to(DEV), b.float().to(DEV)
+    want = L.linear_workspace(M, N, K)
+    assert want > 0 or split != 0 or M * N > 2160 * 2048      # the library wants to split the band shape by itself
+    ws = torch.empty(max(want, 8 * ((M + 255) // 256) * (N // 256) * 256 * 256 * 4), dtype=torch.uint8, device=DEV)
+    tickets = torch.zeros(4096, dtype=torch.int32, device=DEV)
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        out2 = torch.full((M, N), float("nan"), device=DEV) if epilogue == "dual" else None
+        L.linear_ws(ad, wd, bd, out, ws, tickets, split=split, out2=out2)
+        torch.cuda.synchronize()
+        assert int(tickets.abs().sum()) == 0
+        outs.append((out, out2))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if epilogue == "dual":
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert relerr(outs[0][1], ref) < 5e-6
+    assert relerr(outs[0][0].float(), ref) < 5e-3
+    plain = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    L.linear(ad, wd, bd, plain)
+    torch.cuda.synchronize()
+    d = (outs[0][0].float() - plain.float()).abs()
+    assert (d <= plain.float().abs() * 2.0 ** -7 + 1e-6).all()     # at most one bf16 ulp apart
 
 
 def test_linear_broadcast_residual_row_and_strided_views():
@@ -483,8 +544,10 @@ def test_patchify_matches_conv_unfold(P):
     K = (V + 1) * T * P * P
     Kpad = (K + 31) // 32 * 32
     out = torch.full((C * B * Hp * Wp, Kpad), float("nan"), device=DEV)
-    L.patchify(descs, out, 0, K, B, T, C, Hp, Wp, P)
+    word = torch.full((1,), 0.25, device=DEV)    # folded into, not overwritten
+    L.patchify(descs, out, 0, K, B, T, C, Hp, Wp, P, absmax=word)
     torch.cuda.synchronize()
+    assert float(word) == float(out[:, :K].abs().max())   # the guard word of the linears that read `out`
     # reference: normalise, clamp var 1, unfold
     xn = (x[..., :H, :] - loc[:V, :, None, None]) / sc[:V, :, None, None]
     xn[:, :, 1] = xn[:, :, 1].clamp(min=0)

@@ -155,6 +155,54 @@ def test_halo_exchange_over_two_gloo_processes(shifted):
     assert ret.get(timeout=10) < 1e-10
 
 
+def _selftest_worker(rank, world, port, corrupt, ret):
+    import os
+
+    import torch.distributed as dist
+
+    from aurora_amd.engine import native
+    from aurora_amd.engine.engine import Shard
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = native._Transport(Shard(rank, world, None), "cpu")
+    if corrupt and rank == 1:   # a transport that delivers the wrong bytes must be caught by the receiver
+        good = t._wait
+
+        def bad(user, stream):
+            rc = good(user, stream)
+            t.recv[5] ^= 1
+            return rc
+
+        t._wait = bad
+    try:
+        t.selftest(4096)
+        ret.put((rank, "ok", t.exchanges))
+    except RuntimeError as e:
+        ret.put((rank, str(e), t.exchanges))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_transport_selftest_over_three_gloo_processes(corrupt):
+    """What bench.py --gpus N runs before it times anything: every rank sends a rank-stamped pattern to its neighbours through
+    the production `_Transport` (its staging buffers, `_post` / `_wait`, the process group) and verifies what arrived."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_selftest_worker, args=(r, 3, 29670 + int(corrupt), corrupt, ret)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = dict((r, (msg, n)) for r, msg, n in (ret.get(timeout=10) for _ in range(3)))
+    assert all(n == 1 for _, n in got.values())
+    if corrupt:
+        assert got[0][0] == got[2][0] == "ok" and "wrong byte 5 from rank 0" in got[1][0]
+    else:
+        assert all(msg == "ok" for msg, _ in got.values())
+
+
 @pytest.mark.parametrize("res,world", [((4, 24, 24), 2), ((4, 45, 24), 8), ((4, 180, 360), 8)])
 @pytest.mark.parametrize("shifted", [False, True])
 def test_interior_windows_need_no_halo_and_cover_most_of_a_band(res, world, shifted):

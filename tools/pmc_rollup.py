@@ -10,8 +10,10 @@ bench.py and DESIGN.md quote:
                    taken at face value -- it reproduces the algorithmic output bytes of the persistent kernel's 134
                    launches per step to 0.1 % (391 MB).
 """
+import hashlib
 import json
 import sys
+from pathlib import Path
 
 src, dst = sys.argv[1], sys.argv[2]
 build_commit = sys.argv[3] if len(sys.argv) > 3 else None   # commit of the tree the passes profiled (gpurun ships no .git)
@@ -29,6 +31,8 @@ out = {
                     "included (round 1 took x1 for the GEMM: wrong).  FETCH_SIZE counts L2 misses on the fabric side: "
                     "Infinity-Cache hits are included, so this is L2-miss traffic, an upper bound of HBM traffic.",
     "build_commit": build_commit,
+    # bench.py reports `roofline.traffic` only while the GEMM source is the one these passes profiled
+    "gemm_source_sha256": hashlib.sha256((Path(__file__).resolve().parents[1] / "aurora_amd" / "csrc" / "gemm.hip").read_bytes()).hexdigest(),
     "linear_bf16_launches_profiled": tot,
     "linear_bf16_read_bytes_per_launch": 2.0 * w("FETCH_SIZE_per_launch") * 1024,
     "linear_bf16_write_bytes_per_launch": w("WRITE_SIZE_per_launch") * 1024,

@@ -44,11 +44,23 @@ with torch.inference_mode():
     eng.profile_start()
     eng.step(band)
     mine = eng.profile_stop()
+    eng.profile_start()
+    eng.step(band)
+    launches = eng.native.profile_end_list()
 share = (band.band[1] - band.band[0]) / band.full_patch_rows
 rows = []
 for k in sorted(set(single) | set(mine), key=lambda k_: -mine.get(k_, {"ms": 0})["ms"]):
     s, t = single.get(k, {"ms": 0.0, "launches": 0}), mine.get(k, {"ms": 0.0, "launches": 0})
     rows.append({"kind": k, "rank_ms": round(t["ms"], 3), "launches": t["launches"], "share_of_unsharded_ms": round(s["ms"] * share, 3),
                  "ratio": round(t["ms"] / (s["ms"] * share), 2) if s["ms"] else None})
+# per shape (kind + algorithmic work identify it): launches, mean microseconds, TFLOP/s for the linears
+shapes = {}
+for kind, ms, work in launches:
+    n, t = shapes.get((kind, work), (0, 0.0))
+    shapes[(kind, work)] = (n + 1, t + ms)
+by_shape = [{"kind": k, "work": w, "launches": n, "mean_us": round(t / n * 1e3, 1), "total_ms": round(t, 3),
+             **({"tflops": round(w * n / t / 1e9, 0)} if k.startswith("linear") and t > 0 else {})}
+            for (k, w), (n, t) in sorted(shapes.items(), key=lambda kv: -kv[1][1])]
+print(json.dumps({"by_shape": by_shape[:40]}), file=sys.stderr)
 print(json.dumps({"ranks": R, "rank": rank, "row_share": share, "rank_total_ms": round(sum(v["ms"] for v in mine.values()), 2),
                   "share_of_unsharded_total_ms": round(sum(v["ms"] for v in single.values()) * share, 2), "per_kind": rows}, indent=1))
