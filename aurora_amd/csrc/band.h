@@ -31,6 +31,9 @@ bool band_rows(const std::vector<Res>& all_res, const int window[3], int world,
                std::vector<std::vector<std::array<int, 2>>>& rows);
 
 // What one rank needs to run window attention of one block flavour on its band (partition.py:block_plans).
+// candidates the partition search of band_rows tries before it gives up (engine/partition.py: the same number)
+constexpr long BAND_SEARCH_BUDGET = 200000;
+
 struct BandPlan {
   std::vector<int32_t> tok;      // [n_windows][n_tok] index into [own rows | halo rows]; -1 = padding / unseen
   std::vector<uint8_t> grp;      // [n_windows][n_tok] (empty when not shifted)

@@ -96,14 +96,18 @@ bool rows_from_bounds(const std::vector<Res>& all_res, const std::vector<int>& b
 
 // Can every rank get what its windows need from its two neighbours?  Tokens that attend to each other -- a window's
 // positions of one mask group (band_plan below drops the rest) -- must lie on at most two adjacent ranks, in both block
-// flavours at every stage.  Only the latitude structure matters: checked on a grid one window wide.
-bool neighbours_suffice(const std::vector<Res>& all_res, const int window[3],
-                        const std::vector<std::vector<std::array<int, 2>>>& rows) {
+// flavours at every stage.  Only the latitude structure matters (a grid one window wide), and because bands are contiguous
+// and ordered, a set of rows spans the ranks owner[lowest row] .. owner[highest row]: every (window, group) reduces to ONE
+// row interval, and those depend on the grid alone.  They are collected once per search (GroupSpans); a candidate
+// partition then costs a few hundred look-ups instead of rebuilding every stage's window tables (which made an infeasible
+// 12-rank request take minutes to fail).
+struct GroupSpans { std::vector<std::vector<std::array<int, 2>>> per_stage; };   // [stage] -> distinct (lowest, highest) rows
+
+GroupSpans group_spans(const std::vector<Res>& all_res, const int window[3]) {
+  GroupSpans out;
   for (size_t s = 0; s < all_res.size(); ++s) {
     const Res res{all_res[s].c, all_res[s].h, std::min(all_res[s].w, window[2])};
-    std::vector<int> owner(res.h, -1);
-    for (size_t r = 0; r < rows[s].size(); ++r)
-      for (int h = rows[s][r][0]; h < rows[s][r][1]; ++h) owner[h] = (int)r;
+    std::vector<std::array<int, 2>> spans;
     for (int shifted = 0; shifted < 2; ++shifted) {
       const WindowTables t = window_tables(res, window, shifted != 0);
       for (int w = 0; w < t.n_windows; ++w) {
@@ -112,14 +116,30 @@ bool neighbours_suffice(const std::vector<Res>& all_res, const int window[3],
         for (int i = 0; i < t.n_tok; ++i) {
           const int32_t tk = t.tok[(size_t)w * t.n_tok + i];
           if (tk < 0) continue;
-          const int g = t.grp.empty() ? 0 : t.grp[(size_t)w * t.n_tok + i], o = owner[(tk / res.w) % res.h];
-          lo[g] = std::min(lo[g], o);
-          hi[g] = std::max(hi[g], o);
+          const int g = t.grp.empty() ? 0 : t.grp[(size_t)w * t.n_tok + i], h = (tk / res.w) % res.h;
+          lo[g] = std::min(lo[g], h);
+          hi[g] = std::max(hi[g], h);
         }
         for (int g = 0; g < 28; ++g)
-          if (hi[g] - lo[g] > 1) return false;
+          if (hi[g] > lo[g]) spans.push_back({lo[g], hi[g]});
       }
     }
+    std::sort(spans.begin(), spans.end());
+    spans.erase(std::unique(spans.begin(), spans.end()), spans.end());
+    out.per_stage.push_back(std::move(spans));
+  }
+  return out;
+}
+
+bool neighbours_suffice(const GroupSpans& gs, const std::vector<Res>& all_res,
+                        const std::vector<std::vector<std::array<int, 2>>>& rows) {
+  std::vector<int> owner;
+  for (size_t s = 0; s < all_res.size(); ++s) {
+    owner.assign(all_res[s].h, -1);
+    for (size_t r = 0; r < rows[s].size(); ++r)
+      for (int h = rows[s][r][0]; h < rows[s][r][1]; ++h) owner[h] = (int)r;
+    for (const auto& sp : gs.per_stage[s])
+      if (owner[sp[1]] - owner[sp[0]] > 1) return false;
   }
   return true;
 }
@@ -150,17 +170,20 @@ bool band_rows(const std::vector<Res>& all_res, const int window[3], int world,
   const int m_opt = (Hc + world - 1) / world;
   int m_unit = 0;
   for (int r = 0; r < world; ++r) m_unit = std::max(m_unit, bounds[r + 1] - bounds[r]);
-  if (has_rows && (m_unit - m_opt) * 12 <= m_opt && neighbours_suffice(all_res, window, rows)) return true;
+  const GroupSpans gs = group_spans(all_res, window);
+  if (has_rows && (m_unit - m_opt) * 12 <= m_opt && neighbours_suffice(gs, all_res, rows)) return true;
   // Otherwise -- and for thin bands (many ranks for the grid: the 0.4-degree grid on 8), where a window of the aligned split
   // may reach past a whole band -- search the partitions with the smallest largest band, thick bands first, for one whose
   // windows stay within neighbouring ranks.
+  // (BAND_SEARCH_BUDGET candidates, a fraction of a second; engine/partition.py searches the same candidates in the same
+  // order with the same budget, so the two agree on success, on the split found and on giving up)
   std::vector<int> sizes(world, 0);
-  long budget = 2000000;
+  long budget = BAND_SEARCH_BUDGET;
   for (int m = (Hc + world - 1) / world; m <= Hc; ++m) {
     // iterative depth-first search over band sizes 1 .. m that sum to Hc
     int r = 0, remaining = Hc;
     sizes[0] = std::min(m, remaining - (world - 1)) + 1;   // "one above the first candidate"
-    while (r >= 0) {
+    while (r >= 0 && budget >= 0) {
       const int left = world - 1 - r;                      // bands still to size after this one
       int sz = sizes[r] - 1;                               // next candidate for band r
       const int least = std::max(1, remaining - left * m); // smaller would leave too much for the rest
@@ -173,7 +196,7 @@ bool band_rows(const std::vector<Res>& all_res, const int window[3], int world,
         if (sz == remaining && --budget >= 0) {
           std::vector<int> b{0};
           for (int q = 0; q < world; ++q) b.push_back(b.back() + sizes[q]);
-          if (rows_from_bounds(all_res, b, rows, nullptr, nullptr) && neighbours_suffice(all_res, window, rows)) return true;
+          if (rows_from_bounds(all_res, b, rows, nullptr, nullptr) && neighbours_suffice(gs, all_res, rows)) return true;
         }
         sizes[r] = least;                                  // no other size fits the last band
         continue;
@@ -187,6 +210,10 @@ bool band_rows(const std::vector<Res>& all_res, const int window[3], int world,
   if (!has_rows)
     set_error("latitude-band partition: rank %d of %d ends up without rows at stage %d (%d rows)", bad_rank, world, bad_stage,
               all_res[bad_stage].h);
+  else if (budget < 0)
+    set_error("latitude-band partition: none of the first %ld splits of %d coarsest-stage rows over %d ranks (most balanced first) "
+              "keeps every window within two neighbouring ranks; search stopped (bands too thin: use fewer ranks)",
+              (long)BAND_SEARCH_BUDGET, Hc, world);
   else
     set_error("latitude-band partition: no split of %d coarsest-stage rows over %d ranks keeps every window within two "
               "neighbouring ranks (bands too thin)", Hc, world);

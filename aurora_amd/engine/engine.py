@@ -47,12 +47,13 @@ class Engine:
         self.model = model
         self.cfg = cfg = model.config
         p = next(model.parameters())
-        if p.dtype != F32:
+        if p.dtype not in (F32, torch.float64):   # float64 masters are rounded to float32 with a warning (native.py)
             raise NotImplementedError(
                 f"aurora_amd computes in fp32 (or bf16 backbone with autocast=True); parameters "
-                f"are {p.dtype}. Keep the model in float32."
+                f"are {p.dtype}. Keep the model in float32 (or float64)."
             )
         self.device = p.device
+        self._rows_cache: dict = {}
         for heads, dim in zip(cfg.encoder_num_heads + cfg.decoder_num_heads,
                               cfg.stage_dims() + cfg.stage_dims()[::-1]):
             if dim != heads * 64:
@@ -110,11 +111,16 @@ class Engine:
         if not self._capturing:  # (a captured step runs on a batch the hook has already seen)
             batch = model.batch_transform_hook(batch)
         if self.shard is not None:
+            # the caller's own full-grid static fields never change: a gathered forecast hands them back as they came
+            full_static = None
+            if self.shard.gather_output and not isinstance(batch, BandBatch):
+                batch = batch.type(F32).crop(cfg.patch_size).to(self.device)   # (local_band's own conversions are no-ops then)
+                full_static = dict(batch.static_vars)
             band = self.local_band(batch)
             T = next(iter(band.surf_vars.values())).shape[1]
             assert T <= cfg.max_history_size, f"{T} > {cfg.max_history_size}."
             pred = self.native.step(band, upload_time=True, out=None if self.shard.gather_output else out)
-            return self._gather(pred) if self.shard.gather_output else pred
+            return self._gather(pred, full_static) if self.shard.gather_output else pred
         batch = batch.type(F32).crop(cfg.patch_size).to(self.device)
         T = next(iter(batch.surf_vars.values())).shape[1]
         assert T <= cfg.max_history_size, f"{T} > {cfg.max_history_size}."
@@ -140,7 +146,16 @@ class Engine:
                          band=(r0 // P, r1 // P), rank=sh.rank, world=sh.world)
 
     def band_rows_of(self, rank: int, full_patch_rows: int, patch_cols: int) -> tuple[int, int]:
-        """Patch rows [h0, h1) of `rank`'s band (the handle's own partition function; pure host code)."""
+        """Patch rows [h0, h1) of `rank`'s band (the handle's own partition function; pure host code).  Cached per grid:
+        the partition is a search, and a gathered forecast asks for every rank's rows every step."""
+        key = (rank, full_patch_rows, patch_cols)
+        hit = self._rows_cache.get(key)
+        if hit is not None:
+            return hit
+        self._rows_cache[key] = out = self._band_rows_of(rank, full_patch_rows, patch_cols)
+        return out
+
+    def _band_rows_of(self, rank: int, full_patch_rows: int, patch_cols: int) -> tuple[int, int]:
         cfg = self.cfg
         i32 = lambda v: (ctypes.c_int32 * len(v))(*v)  # noqa: E731
         h0, h1 = ctypes.c_int32(), ctypes.c_int32()
@@ -149,9 +164,10 @@ class Engine:
             self.shard.world, rank, 0, ctypes.byref(h0), ctypes.byref(h1)))
         return h0.value, h1.value
 
-    def _gather(self, pred: BandBatch) -> Batch:
+    def _gather(self, pred: BandBatch, full_static=None) -> Batch:
         """Assemble the full fields on every rank with ONE collective: every field of the band is packed into one buffer
-        (bands padded to the tallest), all-gathered, and cut back into place."""
+        (bands padded to the tallest), all-gathered, and cut back into place.  `full_static`: the full-grid static fields
+        the caller passed in -- they never change, so they are handed back instead of being packed and gathered."""
         import torch.distributed as dist
 
         sh, P = self.shard, self.cfg.patch_size
@@ -159,7 +175,7 @@ class Engine:
         rows0 = [self.band_rows_of(r, pred.full_patch_rows, W // P) for r in range(sh.world)]
         heights = [(b - a) * P for a, b in rows0]
         h, h_max, H = heights[sh.rank], max(heights), rows0[-1][1] * P
-        groups = (pred.surf_vars, pred.static_vars, pred.atmos_vars)
+        groups = (pred.surf_vars, {} if full_static is not None else pred.static_vars, pred.atmos_vars)
         items = [(gi, k, v) for gi, d_ in enumerate(groups) for k, v in d_.items()]
         planes = [v.numel() // (h * W) for _, _, v in items]
         mine = torch.zeros((sum(planes), h_max, W), dtype=F32, device=self.device)

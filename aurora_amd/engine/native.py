@@ -226,9 +226,25 @@ class NativeModel:
         handle = ctypes.c_void_p()
         lib._check(L.aurora_hip_create(ctypes.byref(c), ctypes.byref(handle)))
         self._h = handle
+        self.param_dtype = torch.float32
         for name, t in model.state_dict().items():
-            t = t.detach().contiguous()
-            assert t.dtype == torch.float32
+            t = t.detach()
+            if t.dtype == torch.float64:
+                # `model.double()` (the reference's golden test runs so, tests/test_model.py:18-24 upstream; docs/usage.md
+                # callers too): the engine computes in fp32 (bf16 backbone GEMMs under autocast) -- the fp64 masters are
+                # rounded once here, the predictions are returned as float64 like the reference's.  Said out loud, once.
+                if self.param_dtype != torch.float64:
+                    import warnings
+
+                    warnings.warn("aurora_amd: the model's parameters are float64; the HIP engine computes in float32 "
+                                  "(fp32 masters packed from them, predictions cast back to float64). Results match an "
+                                  "fp64 evaluation to fp32 round-off (~1e-6 relative), not to fp64's.", UserWarning, stacklevel=3)
+                self.param_dtype = torch.float64
+                t = t.float()
+            t = t.contiguous()
+            if t.dtype != torch.float32:
+                raise TypeError(f"aurora_amd: parameter '{name}' is {t.dtype}; the HIP engine packs float32 (or float64, "
+                                "rounded to float32) masters -- keep the model in float32 and use `autocast=True` for bf16")
             shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
             lib._check(L.aurora_hip_pack_weights(self._h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim(),
                                                  lib.F32, int(t.is_cuda)))
@@ -421,6 +437,9 @@ class NativeModel:
                                  time=tuple(t + cfg.timestep for t in md.time), rollout_step=md.rollout_step + 1)
         # the prediction lists the variables in the order the reference's does: the inputs' order, except that the
         # ocean-wave variant returns the directions after the other variables (aurora.py:914-932)
+        if self.param_dtype != torch.float32:   # dtype follows the first parameter (aurora.py:277-281 upstream)
+            out_s = [None if t is None else t.to(self.param_dtype) for t in out_s]
+            out_a = [None if t is None else t.to(self.param_dtype) for t in out_a]
         o_s = dict(zip(self.surf_outputs, out_s))
         if self.model.variant == "wave":
             surf_out = {n: o_s[n] for n in self.surf_outputs if o_s[n] is not None}

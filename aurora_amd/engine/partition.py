@@ -50,24 +50,40 @@ def _rows_from_bounds(all_res: list[Res], bounds: list[int]) -> list[list[tuple[
     return out
 
 
-def _neighbours_suffice(all_res: list[Res], window: Res, rows: list[list[tuple[int, int]]]) -> bool:
-    """Tokens that attend to each other -- a window's positions of one mask group -- lie on at most two adjacent ranks, in
-    both block flavours at every stage (only the latitude structure matters: checked on a grid one window wide)."""
-    for s, (C, H, W) in enumerate(all_res):
+SEARCH_BUDGET = 200_000   # candidate partitions tried before giving up (csrc/band.h: BAND_SEARCH_BUDGET)
+
+
+def _group_spans(all_res: list[Res], window: Res) -> list[np.ndarray]:
+    """Per stage, the distinct (lowest, highest) latitude rows of the sets of tokens that attend to each other: a window's
+    positions of one mask group, in both block flavours (only the latitude structure matters: a grid one window wide).
+    They depend on the grid alone -- collected once per search, not per candidate (csrc/band.hip: group_spans)."""
+    out = []
+    for C, H, W in all_res:
         res = (C, H, min(W, window[2]))
-        owner = np.full(H, -1)
-        for r, (h0, h1) in enumerate(rows[s]):
-            owner[h0:h1] = r
+        spans = set()
         for shifted in (False, True):
             tok, grp, _ = geometry.window_tables(res, window, shifted)
-            own = np.where(tok >= 0, owner[(np.maximum(tok, 0) // res[2]) % H], -1)
+            row = np.where(tok >= 0, (np.maximum(tok, 0) // res[2]) % H, -1)
             g = grp if grp is not None else np.zeros_like(tok, dtype=np.uint8)
             for label in np.unique(g):
                 sel = (g == label) & (tok >= 0)
-                hi = np.where(sel, own, -1).max(axis=1)
-                lo = np.where(sel, own, 1 << 30).min(axis=1)
-                if np.any((hi - lo > 1) & sel.any(axis=1)):
-                    return False
+                hi = np.where(sel, row, -1).max(axis=1)
+                lo = np.where(sel, row, 1 << 30).min(axis=1)
+                spans.update((int(a), int(b)) for a, b in zip(lo, hi) if b > a)
+        out.append(np.array(sorted(spans), dtype=np.int64).reshape(-1, 2))
+    return out
+
+
+def _neighbours_suffice(spans: list[np.ndarray], all_res: list[Res], rows: list[list[tuple[int, int]]]) -> bool:
+    """Tokens that attend to each other lie on at most two adjacent ranks at every stage: bands are contiguous and ordered,
+    so a set of rows spans the ranks owner[lowest row] .. owner[highest row]."""
+    for s, (C, H, W) in enumerate(all_res):
+        owner = np.full(H, -1)
+        for r, (h0, h1) in enumerate(rows[s]):
+            owner[h0:h1] = r
+        sp = spans[s]
+        if len(sp) and np.any(owner[sp[:, 1]] - owner[sp[:, 0]] > 1):
+            return False
     return True
 
 
@@ -108,12 +124,19 @@ def band_rows(all_res: list[Res], window: Res, world: int) -> list[list[tuple[in
     rows = _rows_from_bounds(all_res, bounds)
     m_opt, m_unit = -(-Hc // world), max(b1 - b0 for b0, b1 in zip(bounds, bounds[1:]))
     # kept unless badly balanced (largest band more than 1/12 above the smallest possible largest band)
-    if rows is not None and (m_unit - m_opt) * 12 <= m_opt and _neighbours_suffice(all_res, window, rows):
+    spans = _group_spans(all_res, window)
+    if rows is not None and (m_unit - m_opt) * 12 <= m_opt and _neighbours_suffice(spans, all_res, rows):
         return rows
+    budget = SEARCH_BUDGET
     for m in range(-(-Hc // world), Hc + 1):
         for sizes in _compositions(world, Hc, m):
+            budget -= 1
+            if budget < 0:
+                raise ValueError(f"none of the first {SEARCH_BUDGET} splits of {Hc} coarsest-stage rows over {world} ranks (most "
+                                 "balanced first) keeps every window within two neighbouring ranks; search stopped (bands too "
+                                 "thin: use fewer ranks)")
             rows = _rows_from_bounds(all_res, [0] + [int(x) for x in np.cumsum(sizes)])
-            if rows is not None and _neighbours_suffice(all_res, window, rows):
+            if rows is not None and _neighbours_suffice(spans, all_res, rows):
                 return rows
     raise ValueError(f"no split of {Hc} coarsest-stage rows over {world} ranks keeps every window within two neighbouring "
                      "ranks (bands too thin)")

@@ -49,7 +49,8 @@ class Model(metaclass=abc.ABCMeta):
     @torch.inference_mode()
     def run(self, batch: Batch, num_steps: int) -> Generator[Batch, None, None]:
         """Perform `num_steps` prediction steps on the device; the predictions are yielded on the CPU."""
-        self.model.to(self.target_device)   # in place, as upstream
+        if next(self.model.parameters()).device.type != self.target_device.type:
+            self.model.to(self.target_device)   # in place, as upstream (a resident model stays where it is, engine and all)
         batch = batch.to(self.target_device)
         try:
             yield from rollout(self.model, batch, steps=num_steps, to_host=True)

@@ -215,9 +215,14 @@ class Aurora(nn.Module):
         self._engine = None
 
     def _apply(self, fn, *args, **kwargs):
-        # .to() / .double() / .cuda() change storage: drop packed weights.
-        self._engine = None
-        return super()._apply(fn, *args, **kwargs)
+        # .to() / .double() / .cuda() that really change storage drop the packed weights; a no-op `.to(device)` on a model
+        # that is already there (foundry's `Model.run` does one per request) keeps the handle, its weights and workspace
+        stamp = lambda: [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]  # noqa: E731
+        before = stamp()
+        out = super()._apply(fn, *args, **kwargs)
+        if stamp() != before:
+            self._engine = None
+        return out
 
     def load_state_dict(self, *args, **kwargs):
         self._engine = None

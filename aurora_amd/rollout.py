@@ -199,6 +199,8 @@ def write_rollout(model, batch: Batch, steps: int, path_template: str, graph: bo
                 return
             pred, path = item
             try:
+                if not hasattr(pred, "rank"):   # a plain Batch (un-sharded, or gathered): `{rank}` is rank 0, filled HERE --
+                    path = _fill(path, rank=0)  # Batch.to_netcdf would take the braces literally
                 pred.to_netcdf(path)
                 written.append(_fill(path, rank=getattr(pred, "rank", 0)))
             except Exception as e:  # noqa: BLE001  (re-raised in the caller's thread below)

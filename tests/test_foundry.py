@@ -64,8 +64,10 @@ def test_run_yields_the_rollout_on_the_cpu(resident, tmp_path):
     foundry.MLFLOW_ARTIFACTS["served"] = str(ckpt)
     served = Served()
     assert next(served.model.parameters()).device.type == "cpu"
+    engines = []
     for _ in range(2):   # a second run re-uses (resident) or re-packs (default) the weights: same predictions
         got = list(served.run(batch.to("cpu"), 3))
+        engines.append(served.model._engine)
         assert len(got) == 3
         for g, w in zip(got, want):
             assert g.metadata.rollout_step == w.metadata.rollout_step and g.metadata.time == w.metadata.time
@@ -74,3 +76,5 @@ def test_run_yields_the_rollout_on_the_cpu(resident, tmp_path):
             for k, v in w.atmos_vars.items():
                 assert torch.equal(g.atmos_vars[k], v), k
         assert next(served.model.parameters()).device.type == ("cuda" if resident else "cpu")
+    # resident: ONE handle (packed weights, workspace) served both requests; default: the move to the CPU dropped it
+    assert (engines[0] is engines[1] and engines[0] is not None) if resident else engines[1] is None

@@ -155,6 +155,32 @@ def test_halo_exchange_over_two_gloo_processes(shifted):
     assert ret.get(timeout=10) < 1e-10
 
 
+def test_partition_search_is_bounded_and_says_when_it_gave_up():
+    """A rank count the grid cannot carry must fail at once, not after minutes (the check of a candidate costs a few hundred
+    look-ups since the row spans of the mask groups are collected once per grid; both twins stop after the same number of
+    candidates and say so), and the 12- / 16-way splits of the 0.25-degree token grid, which the slow search of round 3 ran
+    out of budget on, are found -- with plans that need neighbours only."""
+    import ctypes
+    import time
+
+    from aurora_amd.engine import lib
+
+    L = lib.load()
+    i32 = lambda v: (ctypes.c_int32 * len(v))(*v)  # noqa: E731
+    h0, h1 = ctypes.c_int32(), ctypes.c_int32()
+    t0 = time.perf_counter()
+    rc = L.aurora_hip_band_partition(3, i32((4, 180, 360)), i32(WINDOW), 24, 0, 0, ctypes.byref(h0), ctypes.byref(h1))
+    assert rc != 0 and time.perf_counter() - t0 < 5.0
+    assert b"search stopped" in L.aurora_hip_last_error() and str(partition.SEARCH_BUDGET).encode() in L.aurora_hip_last_error()
+    all_res = [(4, 180, 360), (4, 90, 180), (4, 45, 90)]
+    for world in (12, 16):
+        rows = partition.band_rows(all_res, WINDOW, world)
+        assert _c_rows(3, (4, 180, 360), WINDOW, world) == [[tuple(r) for r in st] for st in rows]
+        for s, res in enumerate(all_res):
+            for shifted in (False, True):
+                partition.block_plans(res, WINDOW, shifted, tuple(rows[s]))   # raises if a halo row is not a neighbour's
+
+
 def _selftest_worker(rank, world, port, corrupt, ret):
     import os
 
