@@ -43,6 +43,7 @@ struct AttnArgs {
   const void* qkv; const float* bias; void* out;
   const int32_t* tok; const uint8_t* grp;
   int B; int64_t L; int D; int heads; int n_windows; int N;
+  int xcd_order;  // 1: every XCD walks a contiguous range of (window, head) items (the heads of a window run side by side)
   int64_t L_out;  // rows of `out` per batch element; tokens >= L_out (halo rows of a band) are not stored
 };
 
@@ -51,6 +52,35 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// max without the canonicalising `v_max_f32 x, x, x` hipcc puts in front of every operand of fmaxf (it cannot prove that an
+// MFMA result is not a signalling NaN): 63 instructions for the maximum of a lane's 36 scores became 18.  The softmax is
+// VALU-issue-bound (an item costs ~12.5 k SIMD cycles per wave, ~1.7 k of them MFMA), so every instruction per score counts.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// The -100 mask (swin3d.py:357-358) of four keys at once: x holds (key group) ^ (query group) per byte, 0 for the same
+// group.  A key of another group gets -100 * (x byte) instead of -100: x >= 1, and e^-100 relative to the row maximum (a
+// key of the query's own group is always present) is already below fp32's resolution of the sum and rounds to zero in the
+// bf16 probabilities -- nothing observable changes, and the mask costs a byte conversion and an FMA per score
+// (v_cvt_f32_ubyteN, v_fmac) instead of compare + select + add.
+__device__ __forceinline__ void mask4(f32x4& s, uint32_t x) {
+  s.x = fmaf((float)(x & 0xffu), -100.0f * 8.0f, s.x);   // pre-scale: multiplied by 1/8 later
+  s.y = fmaf((float)((x >> 8) & 0xffu), -100.0f * 8.0f, s.y);
+  s.z = fmaf((float)((x >> 16) & 0xffu), -100.0f * 8.0f, s.z);
+  s.w = fmaf((float)(x >> 24), -100.0f * 8.0f, s.w);
+}
+// Row sums on the matrix pipe: O^T = V^T P^T with a V^T tile of ones yields sum_k P[q][k] in every row -- 9 MFMAs of a pipe
+// that idles during the softmax instead of 36 adds and two cross-lane steps; the weights that are normalised are then the
+// bf16 probabilities the P V product really uses (they sum to one exactly).
+__device__ __forceinline__ bf16x4_t ones_bf16x4() { return bf16x4_t{(short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80}; }
+
 // Reductions over the four lanes l, l^16, l^32, l^48 that share a query: gfx950's row / half swaps
 // (v_permlane16_swap, v_permlane32_swap: one VALU slot each) instead of two ds_bpermute round trips through the LDS
 // crossbar.  swap(x, x) leaves {own-or-partner, partner-or-own} in the two results, so op(r.x, r.y) is the pairwise
@@ -58,9 +88,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 typedef unsigned u32x2_sw __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float quad_max(float v) {
   u32x2_sw r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __builtin_fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+  v = vmax2(__uint_as_float(r.x), __uint_as_float(r.y));
   r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __builtin_fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+  return vmax2(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 __device__ __forceinline__ float quad_sum(float v) {
   u32x2_sw r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -88,9 +118,14 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
 
   const int tid = threadIdx.x;
   const int N = FULL ? MAXN : p.N, nt = FULL ? MAXT : (N + 15) >> 4;
-  const int h = blockIdx.x % p.heads;
-  const int w = (blockIdx.x / p.heads) % p.n_windows;
-  const int b = blockIdx.x / (p.heads * p.n_windows);
+  uint32_t item = blockIdx.x;
+  if (p.xcd_order) {   // workgroup b runs on XCD b % 8: give each XCD a contiguous range of items
+    const uint32_t nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = item & 7, idx = item >> 3;
+    item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int h = item % p.heads;
+  const int w = (item / p.heads) % p.n_windows;
+  const int b = item / (p.heads * p.n_windows);
 
   // Token / group tables of this window; the -100 mask only matters if the window really mixes groups.
   int differs = 0;
@@ -202,15 +237,8 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
     if (masked) {
       const uint32_t gq4 = (uint32_t)s_grp[qt * 16 + i16] * 0x01010101u;
 #pragma unroll
-      for (int kt = 0; kt < MAXT; ++kt) {
-        if (FULL || kt < nt) {
-          const uint32_t x = *reinterpret_cast<const uint32_t*>(s_grp + kt * 16 + 4 * g) ^ gq4;
-          st[kt].x += (x & 0x000000ffu) ? -100.0f * 8.0f : 0.f;  // pre-scale: multiplied by 1/8 below
-          st[kt].y += (x & 0x0000ff00u) ? -100.0f * 8.0f : 0.f;
-          st[kt].z += (x & 0x00ff0000u) ? -100.0f * 8.0f : 0.f;
-          st[kt].w += (x & 0xff000000u) ? -100.0f * 8.0f : 0.f;
-        }
-      }
+      for (int kt = 0; kt < MAXT; ++kt)
+        if (FULL || kt < nt) mask4(st[kt], *reinterpret_cast<const uint32_t*>(s_grp + kt * 16 + 4 * g) ^ gq4);
     }
     if (!FULL && N < nt * 16) {  // keys beyond the window in the last tile
       const int kt = nt - 1, k0 = kt * 16 + 4 * g;
@@ -226,11 +254,11 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < MAXT; ++kt)
-      if (FULL || kt < nt) mx = fmaxf(fmaxf(mx, fmaxf(st[kt].x, st[kt].y)), fmaxf(st[kt].z, st[kt].w));
+      if (FULL || kt < nt) mx = vmax3(vmax3(mx, st[kt].x, st[kt].y), st[kt].z, st[kt].w);
     mx = quad_max(mx);
     const float mxs = mx * c_scale;
-    float sum = 0.f;
     u32x2 pk[MAXT];  // packed bf16 probabilities, kept as dwords (bit-cast at the MFMA)
+    f32x4 osum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < MAXT; ++kt) {
       if (FULL || kt < nt) {
@@ -238,14 +266,13 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
         const float e1 = __builtin_amdgcn_exp2f(fmaf(st[kt].y, c_scale, -mxs));
         const float e2 = __builtin_amdgcn_exp2f(fmaf(st[kt].z, c_scale, -mxs));
         const float e3 = __builtin_amdgcn_exp2f(fmaf(st[kt].w, c_scale, -mxs));
-        sum += (e0 + e1) + (e2 + e3);
         pk[kt] = u32x2{pack_bf16x2(e0, e1), pack_bf16x2(e2, e3)};
+        osum = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones_bf16x4(), __builtin_bit_cast(bf16x4_t, pk[kt]), osum, 0, 0, 0);
       } else {
         pk[kt] = u32x2{0u, 0u};
       }
     }
-    sum = quad_sum(sum);
-    const float inv = __builtin_amdgcn_rcpf(sum);
+    const float inv = __builtin_amdgcn_rcpf(osum.x);   // every row of osum holds this lane's query's row sum
 
     // ---- O^T = V^T P^T, 4 d-tiles of 16 ----
     auto pv = [&](int dt) -> u32x2 {
@@ -394,7 +421,12 @@ extern "C" int aurora_hip_window_attention(const void* qkv, const float* qkv_bia
                    "window_attention: unaligned buffer");
   const int64_t blocks = (int64_t)B * n_windows * heads;
   AURORA_CHECK_ARG(blocks < ((int64_t)1 << 31), "window_attention: grid too large");
-  AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens, L_out};
+  // Item order: with many items per launch every XCD walks a contiguous range of (window, head) items, so that the heads of
+  // a window -- 128-byte pieces of the same token rows, i.e. of the same DRAM pages -- are requested side by side by the
+  // CUs of one XCD instead of by eight XCDs at unrelated times: 4.55 -> 4.94 TB/s at stage 0, 4.18 -> 4.58 at stage 1
+  // (isolated); a launch of a few thousand items (stage 2, a latitude band) is latency-bound and keeps the plain order.
+  const int xcd_order = blocks >= 6000 ? 1 : 0;
+  AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens, xcd_order, L_out};
   if (dtype == AURORA_BF16) {
     // one workgroup per (window, head); full 144-token windows store whole 128-byte rows
     if (win_tokens != MAXN)

@@ -81,6 +81,16 @@ struct Shape { const char* name; int64_t M; int N, K, act, weight; };
 
 static std::vector<Shape> shapes_of(const std::string& set) {
   std::vector<Shape> v;
+  if (set.rfind("shape=", 0) == 0) {   // shape=M,N,K,act : one ad-hoc problem (tools/pmc_gemm_fetch.sh profiles one per run)
+    static char nm[64];
+    long long M = 0;
+    int N = 0, K = 0, act = 0;
+    if (sscanf(set.c_str(), "shape=%lld,%d,%d,%d", &M, &N, &K, &act) >= 3) {
+      snprintf(nm, sizeof nm, "%lldx%dx%d", M, N, K);
+      v.push_back({nm, M, N, K, act, 0});
+    }
+    return v;
+  }
   if (set == "step") {   // the un-sharded 0.25-degree step (weight = launches per step)
     v = {{"s0.qkv", 259200, 1536, 512, 0, 12}, {"s0.proj", 259200, 512, 512, 0, 12}, {"s0.fc1", 259200, 2048, 512, 1, 12},
          {"s0.fc2", 259200, 512, 2048, 0, 12}, {"s1.qkv", 64800, 3072, 1024, 0, 20}, {"s1.proj", 64800, 1024, 1024, 0, 20},
