@@ -66,7 +66,6 @@ struct LinearArgs {
   // split-K (linear_kernel_256pp, MODE 1): workgroup b multiplies K-slice b / n_blocks of tile b % n_blocks; slices
   // meet through fp32 slabs (256 KiB per slice and tile) and a ticket per tile -- the last arriver adds up and finishes
   int split; float* slabs; int32_t* tickets;
-  int gn;   // linear_kernel_256pp: n-tiles per group of the tile order
 };
 
 // The problem of a strided batch this workgroup belongs to (blockIdx.y; a plain launch has one problem and zero strides).
@@ -347,26 +346,6 @@ __device__ __forceinline__ void tile_of_block(uint32_t bid, uint32_t nb, uint32_
   }
 }
 
-// The same order with the width of an n-group chosen per launch (linear_kernel_256pp: an XCD's round of 32 concurrent
-// tiles is (32 / gn) m-tiles x gn n-tiles; at K >= 1024 the 8 weight panels of gn = 8 no longer survive in the 4 MiB L2
-// from one round to the next, a narrower group's do).
-__device__ __forceinline__ void tile_of_block_gn(uint32_t gn, uint32_t bid, uint32_t nb, uint32_t tiles_m, uint32_t tiles_n,
-                                                 uint32_t& tile_m, uint32_t& tile_n) {
-  const uint32_t q8 = nb >> 3, r8 = nb & 7;
-  const uint32_t xcd = bid & 7, idx = bid >> 3;
-  const uint32_t logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const uint32_t groups = tiles_n / gn, full = groups * gn, per_group = gn * tiles_m;
-  if (logical < groups * per_group) {
-    const uint32_t grp = logical / per_group, rem = logical - grp * per_group;
-    tile_m = rem / gn;
-    tile_n = grp * gn + (rem - tile_m * gn);
-  } else {
-    const uint32_t rem = logical - groups * per_group, gw = tiles_n - full;
-    tile_m = rem / gw;
-    tile_n = full + (rem - tile_m * gw);
-  }
-}
-
 // Epilogue of the 256 x 256 kernels: a lane owns a row x 16 consecutive features (same ownership as the
 // 128 x 128 kernel) -> bias, activation, fp32 residual, dual-dtype 16-byte stores.
 template <typename T>
@@ -428,27 +407,15 @@ __device__ __forceinline__ void epilogue_256(const LinearArgs& p, f32x4 (&acc)[4
 // its stores and 16.9 us without) -- as long as half the tile's MFMA time.  The ring is dead after the main
 // loop, so each wave borrows 16 KiB of it; LDS rows are XOR-swizzled (piece ^ (row & 7)): conflict-free for the
 // b128 writes (8 rows per lane group) and reads (4 rows x 4 pieces per lane group).
-// PARTS: 1 a wave's 128 x 64 results in one pass (16 KiB of the dead ring); 2 / 4: passes of 64 / 32 rows (8 / 4 KiB per wave)
-// FULL: all 256 rows of the tile exist -- no predicates, exactly 16 stores per lane (the persistent kernel counts them)
-// lds_bias: the tile's 256 bias values in LDS (persistent kernel: no VGPR load may sit in the vector-memory counter)
-template <int PARTS, bool FULL = false>
+template <int PARTS>   // 1: a wave's 128 x 64 results in one pass (16 KiB of the dead ring); 2: two passes of 64 rows (8 KiB)
 __device__ __forceinline__ void epilogue_256_bf16_coalesced(const LinearArgs& p, f32x4 (&acc)[4][8], int64_t m0,
-                                                            int n0, int wm, int wn, int wave, int lane, char* smem,
-                                                            const float* lds_bias = nullptr) {
+                                                            int n0, int wm, int wn, int wave, int lane, char* smem) {
   const int i16 = lane & 15, g = lane >> 4;
   char* mine = smem + wave * (16384 / PARTS);
   const int nbase = n0 + wn * 64 + 16 * g;
   float bias_v[16];
-  if (lds_bias) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b4 = p.bias ? reinterpret_cast<const f32x4*>(lds_bias + wn * 64 + 16 * g)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-      bias_v[4 * q] = b4.x; bias_v[4 * q + 1] = b4.y; bias_v[4 * q + 2] = b4.z; bias_v[4 * q + 3] = b4.w;
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
-  }
+  for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
   const int rr = lane >> 3, cc = lane & 7;
   bf16_t* cbase = reinterpret_cast<bf16_t*>(p.C) + n0 + wn * 64 + cc * 8;
 #pragma unroll
@@ -487,7 +454,7 @@ __device__ __forceinline__ void epilogue_256_bf16_coalesced(const LinearArgs& p,
       const int row = it * 8 + rr;
       const u32x4 d = *reinterpret_cast<const u32x4*>(mine + row * 128 + ((cc ^ rr) << 4));
       const int64_t m = m0 + wm * 128 + part * (128 / PARTS) + row;
-      if (FULL || m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
+      if (m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
     }
   }
 }
@@ -734,52 +701,6 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
 // DMA of stage s+3 in L(s) overwrites the buffer of stage s-1, whose last reader (a late wave's L(s-1), finished with
 // lgkmcnt(0) before its barrier) is at least one barrier in the past for early and late waves alike.
 // =================================================================================================
-// Register-only epilogue of the plain bf16 -> bf16 linears: no LDS, so the ring may already be receiving the NEXT tile
-// (persistent form below).  A lane owns, per fragment row, 16 consecutive features = two 16-byte pieces (2g, 2g + 1) of
-// the 128-byte row segment its wave column covers.  Lanes i16 and i16 ^ 8 of a 16-lane row trade one piece each (a DPP
-// rotation by 8): then the first store of a fragment writes rows 0-7 -- lanes i16 < 8 piece 2g of their own row, lanes
-// i16 >= 8 piece 2g + 1 of row i16 - 8 --, the second rows 8-15: every store instruction covers eight WHOLE 128-byte
-// rows, the footprint of the LDS-transposed epilogue without its 32 KiB of LDS round trip per wave.
-// FULL: all 256 rows of the tile exist -- no predicates, exactly 16 stores per lane (the persistent kernel counts them).
-template <bool FULL>
-__device__ __forceinline__ void epilogue_256_bf16_rows(const LinearArgs& p, f32x4 (&acc)[4][8], const float (&bias_v)[16],
-                                                       int64_t m0, int n0, int wm, int wn, int lane) {
-  const int i16 = lane & 15, g = lane >> 4;
-  const bool upper = i16 >= 8;
-  bf16_t* const cbase = reinterpret_cast<bf16_t*>(p.C) + n0 + wn * 64 + (2 * g + (upper ? 1 : 0)) * 8;
-  auto ror8 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, true); };   // row_ror:8
-#pragma unroll
-  for (int fm = 0; fm < 8; ++fm) {
-    float v[16];
-#pragma unroll
-    for (int fn = 0; fn < 4; ++fn) {
-      v[4 * fn + 0] = acc[fn][fm].x + bias_v[4 * fn + 0];
-      v[4 * fn + 1] = acc[fn][fm].y + bias_v[4 * fn + 1];
-      v[4 * fn + 2] = acc[fn][fm].z + bias_v[4 * fn + 2];
-      v[4 * fn + 3] = acc[fn][fm].w + bias_v[4 * fn + 3];
-    }
-    if (p.act == AURORA_ACT_GELU) {   // (packed form of gelu_for<bf16_t>: same operations, same bits)
-#pragma unroll
-      for (int t = 0; t < 16; t += 2) {
-        const f32x2_hw r = gelu_sig2(f32x2_hw{v[t], v[t + 1]});
-        v[t] = r.x;
-        v[t + 1] = r.y;
-      }
-    } else if (p.act == AURORA_ACT_SILU) {
-#pragma unroll
-      for (int t = 0; t < 16; ++t) v[t] = v[t] / (1.0f + expf(-v[t]));
-    }
-    const u32x4 pc0 = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-    const u32x4 pc1 = u32x4{pack_bf16x2(v[8], v[9]), pack_bf16x2(v[10], v[11]), pack_bf16x2(v[12], v[13]), pack_bf16x2(v[14], v[15])};
-    const u32x4 give = upper ? pc0 : pc1;   // what the partner lane stores for me
-    const u32x4 got = u32x4{ror8(give.x), ror8(give.y), ror8(give.z), ror8(give.w)};
-    const int64_t ra = m0 + wm * 128 + 16 * fm + (i16 & 7), rb = ra + 8;
-    const u32x4 da = upper ? got : pc0, db = upper ? pc1 : got;
-    if (FULL || ra < p.M) __builtin_nontemporal_store(da, reinterpret_cast<u32x4*>(cbase + ra * p.ldc));
-    if (FULL || rb < p.M) __builtin_nontemporal_store(db, reinterpret_cast<u32x4*>(cbase + rb * p.ldc));
-  }
-}
-
 // 16 bytes written THROUGH to memory (sc1): the payload of an in-launch hand-off needs no release fence then, only the
 // writing wave's own `s_waitcnt vmcnt(0)` before the flag (MI355X guide, "publish-large": 3.0 against 8.2 us per 64 KiB).
 // hipcc does not count an asm store: the callers drain explicitly.
@@ -788,31 +709,24 @@ __device__ __forceinline__ void store_through(float* dst, f32x4 v) {
 }
 
 constexpr int PP_LDS = NSTAGE2 * STAGE2;            // the ring: 128 KiB
-constexpr int PP_LDS_PERSIST = PP_LDS + 2 * 1024;   // + two bias rows of 256 floats (this tile's, the next tile's)
 
-// MODE 0: one workgroup per tile.
-// MODE 1: split-K.  Launches with fewer tiles than CUs and a long K (a latitude band's coarse stages: 72 tiles, K = 8192)
+// SPLIT: split-K.  Launches with fewer tiles than CUs and a long K (a latitude band's coarse stages: 72 tiles, K = 8192)
 //   cut every tile's K range into `split` slices, one workgroup each.  A slice publishes its fp32 accumulators to its
 //   slab (write-through stores, drained), takes a ticket of the tile; whoever draws the last ticket -- no workgroup ever
 //   waits for another, so nothing depends on dispatch order or co-residency -- adds the slices up IN SLICE ORDER (two
 //   slices: its registers + the other slab, commutative; more: all slabs from memory, its own included, so that the sum
 //   does not depend on who came last), resets the ticket for the next launch and runs the ordinary epilogue.
-// MODE 2: persistent.  gridDim.x workgroups walk over the tiles (tile = block + i * grid, the same XCD-aware order).
-//   A 256 x 256 tile at K = 512 holds ~8 us of MFMA work and takes ~19: ~2.5 us until the first K-stage of a cold tile
-//   has arrived, ~5 in the epilogue.  Here the NEXT tile's bias row and first four K-stages are requested as soon as
-//   the ring is dead, before the epilogue -- which therefore must not touch LDS (epilogue_256_bf16_rows; the bias comes
-//   through LDS-DMA into its own 2 x 1 KiB so that no VGPR load sits in the counter) -- and the next main loop starts
-//   on data that arrived meanwhile.  vmcnt retires in order and counts stores too: the 16 result stores a lane issues
-//   AFTER the next prologue sit between that prologue and the stages issued inside the next loop, so the tile-start wait
-//   and the first three steps wait with their immediates raised by 16 ("stage s+1 has landed" = at most the younger
-//   DMA + 16 stores outstanding); from the fourth step on the stores are older than everything waited for.  That count
-//   is exact only for tiles with 256 valid rows (unpredicated stores); a ragged last m-tile drains the counter instead.
-//   With EPI 0 the persistent form keeps the LDS-transposed epilogue: the next tile's prologue fills only stages 0-2,
-//   the buffer of stage 3 (32 KiB: four passes of 32 rows per wave) belongs to the epilogue, and stage 3 is requested in
-//   L(0) of the next main loop -- after the tile-start barrier, i.e. after every wave's epilogue -- where the one-tile
-//   kernel's L(0) requests nothing.  Counter: 12 DMA + 16 stores behind them, S3 behind the stores.
-// EPI: 0 results transposed through the (dead) ring, 1 register-only epilogue.
-template <int MODE, int EPI>
+// Built, measured and deleted again in round 4 (profiles/r04_ab_gemm_variants_isolated.log, r04_ab_gemm_persistent_instep.json):
+//   * a persistent form (workgroups walk over tiles; the next tile's bias row and first K-stages are requested before the
+//     epilogue, which keeps the buffer of stage 3 for its transposition; counted waits raised by the 16 result stores that
+//     sit behind the prologue in the in-order counter): -0.8 % over the step's shapes in isolation (-2...-4 % on the
+//     K = 512 ones), 134.6 against 134.2 ms inside the step -- the cold start of a tile is not what its fixed cost is;
+//   * a register-only epilogue (lanes i16 and i16 ^ 8 trade 16-byte pieces by a DPP rotation, stores cover whole 128-byte
+//     rows): +1 % -- a 16-lane group then writes eight 32-byte pieces, the LDS-transposed form two whole rows;
+//   * narrower n-groups of the tile order (4 or 2 n-tiles instead of 8, so that the weight panels of a round might survive
+//     in L2 at K >= 1024): L2 -> fabric reads unchanged (-4 %; the activation panels streaming through evict them anyway),
+//     time unchanged (profiles/r04_pmc_gemm_fetch_by_group_width.txt).
+template <bool SPLIT>
 __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearArgs p_in) {
   const LinearArgs p = batch_problem(p_in);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -820,55 +734,45 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearA
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;   // waves w and w+4 share a SIMD; wm = 1 runs one phase behind
-  const uint32_t nb = (uint32_t)p.n_blocks, tiles_n = (uint32_t)p.tiles_n, tiles_m = nb / tiles_n;
+  const uint32_t nb = (uint32_t)p.n_blocks;
 
   uint32_t item = blockIdx.x;   // tile, in launch order
   int kb = 0, nt = p.k_tiles, part = 0;
-  if constexpr (MODE == 1) {
+  if constexpr (SPLIT) {
     part = (int)(item / nb);
     item -= (uint32_t)part * nb;
     kb = (int)((int64_t)part * p.k_tiles / p.split);
     nt = (int)((int64_t)(part + 1) * p.k_tiles / p.split) - kb;   // >= 4 (dispatch)
   }
+  uint32_t tile_m, tile_n;
+  tile_of_block(item, nb, nb / (uint32_t)p.tiles_n, (uint32_t)p.tiles_n, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM2;
+  const int n0 = (int)tile_n * BN2;
 
-  struct Tile { int64_t m0; int n0; const char* sx[2]; const char* sw[2]; };
-  auto locate = [&](uint32_t it) {
-    Tile t;
-    uint32_t tile_m, tile_n;
-    tile_of_block_gn((uint32_t)p.gn, it, nb, tiles_m, tiles_n, tile_m, tile_n);
-    t.m0 = (int64_t)tile_m * BM2;
-    t.n0 = (int)tile_n * BN2;
+  const char* src_x[2];
+  const char* src_w[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int id = r * THREADS2 + tid;
-      const int row = id >> 2, c = id & 3;
-      int64_t gm = t.m0 + row;
-      gm = gm < p.M ? gm : p.M - 1;
-      int gn = t.n0 + row;
-      gn = gn < p.N ? gn : p.N - 1;
-      t.sx[r] = p.A + gm * p.lda_b + ((c ^ swz2_x(row)) << 4) + (int64_t)kb * ROW2;
-      t.sw[r] = p.W + (int64_t)gn * p.ldw_b + ((c ^ swz2_w(row)) << 4) + (int64_t)kb * ROW2;
-    }
-    return t;
-  };
-  auto stage = [&](const Tile& t, int kt) {
+  for (int r = 0; r < 2; ++r) {
+    const int id = r * THREADS2 + tid;
+    const int row = id >> 2, c = id & 3;
+    int64_t gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + row;
+    gn = gn < p.N ? gn : p.N - 1;
+    src_x[r] = p.A + gm * p.lda_b + ((c ^ swz2_x(row)) << 4) + (int64_t)kb * ROW2;
+    src_w[r] = p.W + (int64_t)gn * p.ldw_b + ((c ^ swz2_w(row)) << 4) + (int64_t)kb * ROW2;
+  }
+  auto stage = [&](int kt) {
     const int64_t koff = (int64_t)kt * ROW2;
     char* base = smem + (kt & (NSTAGE2 - 1)) * STAGE2;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.sx[r] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[r] + koff),
                                        (lds_ptr_t)(base + (r * THREADS2 + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
     for (int r = 0; r < 2; ++r)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.sw[r] + koff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
                                        (lds_ptr_t)(base + OPER2 + (r * THREADS2 + wave * 64) * 16), 16, 0, 0);
-  };
-  // MODE 2: the tile's 256 bias values into bias row `buf` of LDS, 4 bytes per lane (waves w and w + 4 write the same 256
-  // bytes with the same values, so that every wave issues the same number of vector-memory instructions)
-  auto bias_dma = [&](const Tile& t, int buf) {
-    if (p.bias)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + t.n0 + wn * 64 + lane),
-                                       (lds_ptr_t)(smem + PP_LDS + buf * 1024 + wn * 256), 4, 0, 0);
   };
   const int i16 = lane & 15, g = lane >> 4;
   int off_x[8], off_w[4];
@@ -882,170 +786,101 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearA
     const int row = wn * 64 + 16 * (i16 >> 2) + 4 * f + (i16 & 3);
     off_w[f] = OPER2 + row * ROW2 + ((g ^ swz2_w(row)) << 4);
   }
+  f32x4 acc[4][8];  // [fn][fm]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  stage(0);
+  stage(1);
+  stage(2);
+  stage(3);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // stage 0 is complete
+  asm volatile("" ::: "memory");
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
 
-  constexpr bool LATE3 = MODE == 2 && EPI == 0;   // stage 3 is requested in L(0), its buffer is the epilogue's until then
-  Tile cur = locate(item);
-  int bbuf = 0;
-  if constexpr (MODE == 2) bias_dma(cur, 0);
-  stage(cur, 0);
-  stage(cur, 1);
-  stage(cur, 2);
-  if constexpr (!LATE3) stage(cur, 3);
-  bool pend = false;   // MODE 2: 16 result stores of the previous tile sit behind this tile's prologue in the counter
-  for (;;) {
-    if constexpr (LATE3) {
-      if (pend) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      if (MODE == 2 && pend) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  for (int s = 0; s < nt; ++s) {
+    // ---- L(s): fragments of stage s, refill the ring, settle what the next barrier publishes ----
+    u32x4 fw[4], fx[8];
+    {
+      const char* buf = smem + (s & (NSTAGE2 - 1)) * STAGE2;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) fw[f] = *reinterpret_cast<const u32x4*>(buf + off_w[f]);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) fx[f] = *reinterpret_cast<const u32x4*>(buf + off_x[f]);
     }
-    __builtin_amdgcn_s_barrier();   // stage 0 (and the bias row) is complete
+    if (s >= 1 && s + 3 < nt) stage(s + 3);   // into the buffer of stage s-1
+    if (s + 3 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // own pieces of stage s+1 have landed
+    else if (s + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (wm == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
-    f32x4 acc[4][8];  // [fn][fm]
+    // ---- M(s): the matrix pipe is this wave's alone ----
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int fm = 0; fm < 8; ++fm)
 #pragma unroll
-      for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = Mma<bf16_t>::run(fw[fn], fx[fm], acc[fn][fm]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // the early half waits for the late half's last phase: the ring is dead
+  asm volatile("" ::: "memory");
 
-    for (int s = 0; s < nt; ++s) {
-      // ---- L(s): fragments of stage s, refill the ring, settle what the next barrier publishes ----
-      u32x4 fw[4], fx[8];
-      {
-        const char* buf = smem + (s & (NSTAGE2 - 1)) * STAGE2;
+  if constexpr (SPLIT) {
+    // ---- publish this slice, take a ticket; the last arriver combines ----
+    float* const slab0 = p.slabs + (int64_t)item * p.split * (BM2 * BN2);
+    const int64_t mine_off = (int64_t)(wave * 32 * 64 + lane) * 4;
+    {
+      float* const mine = slab0 + (int64_t)part * (BM2 * BN2) + mine_off;
 #pragma unroll
-        for (int f = 0; f < 4; ++f) fw[f] = *reinterpret_cast<const u32x4*>(buf + off_w[f]);
+      for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
-        for (int f = 0; f < 8; ++f) fx[f] = *reinterpret_cast<const u32x4*>(buf + off_x[f]);
-      }
-      if ((LATE3 || s >= 1) && s + 3 < nt) stage(cur, s + 3);   // into the buffer of stage s-1
-      if (s + 3 < nt) {   // own pieces of stage s+1 have landed
-        if (MODE == 2 && pend && s < (LATE3 ? 2 : 3)) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // (nt >= 8: dispatch)
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else if (s + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      // ---- M(s): the matrix pipe is this wave's alone ----
-#pragma unroll
-      for (int fm = 0; fm < 8; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) acc[fn][fm] = Mma<bf16_t>::run(fw[fn], fx[fm], acc[fn][fm]);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+        for (int fm = 0; fm < 8; ++fm) store_through(mine + (fn * 8 + fm) * 256, acc[fn][fm]);
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();   // the early half waits for the late half's last phase: the ring is dead
-    asm volatile("" ::: "memory");
-
-    if constexpr (MODE == 2) {
-      const uint32_t nxt_item = item + gridDim.x;
-      const bool has_next = nxt_item < nb;
-      Tile nxt = cur;
-      if (has_next) {
-        nxt = locate(nxt_item);
-        bias_dma(nxt, bbuf ^ 1);
-        stage(nxt, 0);
-        stage(nxt, 1);
-        stage(nxt, 2);
-        if constexpr (!LATE3) stage(nxt, 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores ...
+    __syncthreads();                                    // ... before ONE lane takes the ticket
+    int* const s_ticket = reinterpret_cast<int*>(smem);
+    if (tid == 0) *s_ticket = __hip_atomic_fetch_add(p.tickets + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *s_ticket;
+    if (ticket != p.split - 1) return;   // (uniform) someone else will finish this tile
+    if (tid == 0) __hip_atomic_store(p.tickets + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's stale L1 lines, once
+    __syncthreads();
+    const float* const src = slab0 + mine_off;
+    // Two slices: registers + the other slab (commutative).  More: every slab from memory, this one's own included,
+    // in slice order -- the sum must not depend on who drew the last ticket.  Eight loads in flight per lane (the
+    // accumulators hold 128 registers; the fence keeps hipcc from hoisting a slab's 32 loads above the first add).
+    const bool two = p.split == 2;
+    if (!two) {
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < 8; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int j = 0; j < p.split; ++j) {
+      if (two && j == part) continue;
+      const float* const o = src + (int64_t)j * (BM2 * BN2);
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) {
+        f32x4 t[8];
+#pragma unroll
+        for (int fm = 0; fm < 8; ++fm) t[fm] = *reinterpret_cast<const f32x4*>(o + (fn * 8 + fm) * 256);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int fm = 0; fm < 8; ++fm) acc[fn][fm] += t[fm];
       }
-      const float* const lds_bias = reinterpret_cast<const float*>(smem + PP_LDS + bbuf * 1024);
-      const bool full = cur.m0 + BM2 <= p.M;   // (uniform)
-      if constexpr (EPI == 0) {
-        char* const epi = smem + 3 * STAGE2;
-        if (full) {
-          epilogue_256_bf16_coalesced<4, true>(p, acc, cur.m0, cur.n0, wm, wn, wave, lane, epi, lds_bias);
-        } else {
-          epilogue_256_bf16_coalesced<4, false>(p, acc, cur.m0, cur.n0, wm, wn, wave, lane, epi, lds_bias);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // an unknown number of stores was issued: nothing left to count
-        }
-      } else {
-        float bias_v[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 b4 = p.bias ? reinterpret_cast<const f32x4*>(lds_bias + wn * 64 + 16 * g)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
-          bias_v[4 * q] = b4.x; bias_v[4 * q + 1] = b4.y; bias_v[4 * q + 2] = b4.z; bias_v[4 * q + 3] = b4.w;
-        }
-        if (full) {
-          epilogue_256_bf16_rows<true>(p, acc, bias_v, cur.m0, cur.n0, wm, wn, lane);
-        } else {
-          epilogue_256_bf16_rows<false>(p, acc, bias_v, cur.m0, cur.n0, wm, wn, lane);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-      }
-      if (!has_next) return;
-      pend = full;
-      cur = nxt;
-      item = nxt_item;
-      bbuf ^= 1;
-      continue;
-    } else {
-      if constexpr (MODE == 1) {
-        // ---- publish this slice, take a ticket; the last arriver combines ----
-        float* const slab0 = p.slabs + (int64_t)item * p.split * (BM2 * BN2);
-        const int64_t mine_off = (int64_t)(wave * 32 * 64 + lane) * 4;
-        {
-          float* const mine = slab0 + (int64_t)part * (BM2 * BN2) + mine_off;
-#pragma unroll
-          for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-            for (int fm = 0; fm < 8; ++fm) store_through(mine + (fn * 8 + fm) * 256, acc[fn][fm]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores ...
-        __syncthreads();                                    // ... before ONE lane takes the ticket
-        int* const s_ticket = reinterpret_cast<int*>(smem);
-        if (tid == 0) *s_ticket = __hip_atomic_fetch_add(p.tickets + item, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int ticket = *s_ticket;
-        if (ticket != p.split - 1) return;   // (uniform) someone else will finish this tile
-        if (tid == 0) __hip_atomic_store(p.tickets + item, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
-        if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's stale L1 lines, once
-        __syncthreads();
-        const float* const src = slab0 + mine_off;
-        // Two slices: registers + the other slab (commutative).  More: every slab from memory, this one's own included,
-        // in slice order -- the sum must not depend on who drew the last ticket.  Eight loads in flight per lane (the
-        // accumulators hold 128 registers; the fence keeps hipcc from hoisting a slab's 32 loads above the first add).
-        const bool two = p.split == 2;
-        if (!two) {
-#pragma unroll
-          for (int fn = 0; fn < 4; ++fn)
-#pragma unroll
-            for (int fm = 0; fm < 8; ++fm) acc[fn][fm] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        for (int j = 0; j < p.split; ++j) {
-          if (two && j == part) continue;
-          const float* const o = src + (int64_t)j * (BM2 * BN2);
-#pragma unroll
-          for (int fn = 0; fn < 4; ++fn) {
-            f32x4 t[8];
-#pragma unroll
-            for (int fm = 0; fm < 8; ++fm) t[fm] = *reinterpret_cast<const f32x4*>(o + (fn * 8 + fm) * 256);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int fm = 0; fm < 8; ++fm) acc[fn][fm] += t[fm];
-          }
-        }
-      }
-      if (p.C2 == nullptr && p.res == nullptr && p.vec_store) {   // (uniform)
-        if constexpr (EPI == 0) {
-          epilogue_256_bf16_coalesced<1>(p, acc, cur.m0, cur.n0, wm, wn, wave, lane, smem);
-        } else {
-          float bias_v[16];
-          const int nbase = cur.n0 + wn * 64 + 16 * g;
-#pragma unroll
-          for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
-          epilogue_256_bf16_rows<false>(p, acc, bias_v, cur.m0, cur.n0, wm, wn, lane);
-        }
-        return;
-      }
-      epilogue_256<bf16_t>(p, acc, cur.m0, cur.n0, wm, wn, i16, g);
-      return;
     }
   }
+  if (p.C2 == nullptr && p.res == nullptr && p.vec_store) {   // (uniform)
+    epilogue_256_bf16_coalesced<1>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+    return;
+  }
+  epilogue_256<bf16_t>(p, acc, m0, n0, wm, wn, i16, g);
 }
 
 constexpr int MID_LDS = 3 * (BM2 + 128) * ROW2;   // 256 x 128 tiles: three stages of 24 KiB, two workgroups per CU
@@ -1826,12 +1661,7 @@ namespace {
 // ticket per tile (zero on entry, left zero).
 struct SplitWs { float* slabs; int64_t slab_bytes; int32_t* tickets; int n_tickets; int split; };
 
-// Development switches of the bf16 ping-pong kernel, read once (A/B runs): AURORA_GEMM_PP bit 0 register-only epilogue,
-// bit 1 persistent form for short K; AURORA_GEMM_SPLIT forces a K split (0 = never, unset = cost rule).
-int pp_options() {
-  static const int v = [] { const char* e = getenv("AURORA_GEMM_PP"); return e ? atoi(e) : 2; }();
-  return v;
-}
+// AURORA_GEMM_SPLIT (read once): forces a K split for A/B runs (0 = never, unset = the rule below).
 int split_override() {
   static const int v = [] { const char* e = getenv("AURORA_GEMM_SPLIT"); return e ? atoi(e) : -1; }();
   return v;
@@ -2001,11 +1831,6 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
 
   p.bs_a = stride_a * es; p.bs_w = stride_w * es; p.bs_c = stride_c * es; p.bs_bias = stride_bias;
   p.split = ksplit; p.slabs = ksplit > 1 ? ws->slabs : nullptr; p.tickets = ksplit > 1 ? ws->tickets : nullptr;
-  {
-    static const int gn_env = [] { const char* e = getenv("AURORA_GEMM_GN"); return e ? atoi(e) : 0; }();   // A/B: 0 = rule
-    static const int gn_k = [] { const char* e = getenv("AURORA_GEMM_GN_K"); return e ? atoi(e) : 1 << 30; }();
-    p.gn = gn_env > 0 && K >= gn_k ? gn_env : 8;
-  }
   dim3 grid((unsigned)p.n_blocks, (unsigned)batch);
   static bool attr_done_dev[64] = {false};   // function attributes are per device
   bool& attr_done = attr_done_dev[current_device() & 63];
@@ -2015,12 +1840,8 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<float, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256<bf16_t, 2, 3, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, MID_LDS);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_PERSIST);
-    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_PERSIST);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256pp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256_f32x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE2 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_f32pp<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, VNST * VSTAGE);
@@ -2063,26 +1884,11 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
       hipLaunchKernelGGL(linear_kernel_256_f32x3<3>, grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (dtype == AURORA_F32)
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
-    else if (ksplit > 1) {     // ping-pong main loop, one workgroup per K-slice of a tile
-      const dim3 g((unsigned)(p.n_blocks * ksplit));
-      if (pp_options() & 1) hipLaunchKernelGGL((linear_kernel_256pp<1, 1>), g, dim3(THREADS2), PP_LDS, as_stream(stream), p);
-      else hipLaunchKernelGGL((linear_kernel_256pp<1, 0>), g, dim3(THREADS2), PP_LDS, as_stream(stream), p);
-    } else if (p.k_tiles >= 4) {   // ping-pong main loop
-      const int64_t cus8 = device_cus() / 8 * 8;
-      const bool plain = C2 == nullptr && residual == nullptr && vec;
-      // persistent form: short K (the per-tile fixed cost is what it hides), more tiles than CUs, the register-only epilogue
-      const int kmax = (pp_options() & 4) ? 64 : 32;
-      if ((pp_options() & 2) && plain && batch == 1 && p.k_tiles >= 8 && p.k_tiles <= kmax && p.n_blocks > cus8 && cus8 > 0) {
-        if (pp_options() & 1)
-          hipLaunchKernelGGL((linear_kernel_256pp<2, 1>), dim3((unsigned)cus8), dim3(THREADS2), PP_LDS_PERSIST, as_stream(stream), p);
-        else
-          hipLaunchKernelGGL((linear_kernel_256pp<2, 0>), dim3((unsigned)cus8), dim3(THREADS2), PP_LDS_PERSIST, as_stream(stream), p);
-      }
-      else if (pp_options() & 1)
-        hipLaunchKernelGGL((linear_kernel_256pp<0, 1>), grid, dim3(THREADS2), PP_LDS, as_stream(stream), p);
-      else
-        hipLaunchKernelGGL((linear_kernel_256pp<0, 0>), grid, dim3(THREADS2), PP_LDS, as_stream(stream), p);
-    } else
+    else if (ksplit > 1)       // ping-pong main loop, one workgroup per K-slice of a tile
+      hipLaunchKernelGGL(linear_kernel_256pp<true>, dim3((unsigned)(p.n_blocks * ksplit)), dim3(THREADS2), PP_LDS, as_stream(stream), p);
+    else if (p.k_tiles >= 4)   // ping-pong main loop, one workgroup per tile
+      hipLaunchKernelGGL(linear_kernel_256pp<false>, grid, dim3(THREADS2), PP_LDS, as_stream(stream), p);
+    else
       hipLaunchKernelGGL((linear_kernel_256<bf16_t, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
   } else {
     if (dtype == AURORA_F32)

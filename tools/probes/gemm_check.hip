@@ -5,9 +5,10 @@
 //
 //   hipcc --offload-arch=gfx950 -O2 tools/probes/gemm_check.hip -o tools/probes/gemm_check -Laurora_amd/_lib -laurora_hip \
 //         -Wl,-rpath,'$ORIGIN/../../aurora_amd/_lib'
-//   AURORA_GEMM_PP=0|1|3 tools/probes/gemm_check [set ...]        sets: step band8 band4 band2 split small
-// The kernel variant is a process-wide development switch of the library (AURORA_GEMM_PP, AURORA_GEMM_SPLIT), so an A/B
-// is two runs of this binary.
+//   tools/probes/gemm_check [set ...]        sets: step band8 band4 band2 small, or shape=M,N,K[,act]
+//   CHECK_NO_WS=1 no scratch is lent (no split-K); CHECK_SPLIT=s forces s K-slices; CHECK_REPS=n timed launches
+// (Round 4's A/B of the persistent / register-only-epilogue / n-group variants ran this binary under the development
+// switches those variants had -- commits 4e8846e .. 8f2b2a1; the logs are profiles/r04_ab_gemm_*.)
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -140,8 +141,8 @@ int main(int argc, char** argv) {
   HIP_OK(hipMalloc(&tickets, 4096 * 4));
   HIP_OK(hipMemset(tickets, 0, 4096 * 4));
   HIP_OK(hipMalloc(&err, 4));
-  printf("# AURORA_GEMM_PP=%s AURORA_GEMM_SPLIT=%s CHECK_SPLIT=%d ws=%d\n", getenv("AURORA_GEMM_PP") ? getenv("AURORA_GEMM_PP") : "-",
-         getenv("AURORA_GEMM_SPLIT") ? getenv("AURORA_GEMM_SPLIT") : "-", forced_split, (int)use_ws);
+  printf("# AURORA_GEMM_SPLIT=%s CHECK_SPLIT=%d ws=%d\n", getenv("AURORA_GEMM_SPLIT") ? getenv("AURORA_GEMM_SPLIT") : "-", forced_split,
+         (int)use_ws);
   int bad = 0;
   for (const auto& set : sets) {
     double tot_us = 0, tot_fl = 0;
