@@ -173,7 +173,11 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-template <typename T, int HDIM>
+// QC: queries taken together, so that a column's keys / values are read once per chunk of QC queries, not once per query.
+// Chosen from Lq at launch: 3 for the encoder's three latent queries (a chunk of 4 computed a fourth, discarded, query: a
+// third more arithmetic), 7 for the decoder's thirteen level queries (7 + 6: two passes over the three keys instead of four,
+// and 14 slots for 13 queries instead of 16), 4 otherwise.
+template <typename T, int HDIM, int QC>
 __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs p) {
   constexpr int LPG = HDIM / 4;   // lanes per (column, head)
   const int inner = p.heads * HDIM;
@@ -189,8 +193,6 @@ __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs
   const bool pairs = std::is_same<T, float>::value && p.pair_guard != nullptr && *p.pair_guard < p.pair_limit;   // (uniform)
   const T* kv0 = reinterpret_cast<const T*>(p.kv) + (b * p.kv_bstride + l) * (2 * (int64_t)inner) + h * HDIM + d0;
   const int64_t kv_step = p.kv_lstride * (2 * (int64_t)inner);
-  // Queries are taken four at a time so that a column's keys / values are read once per chunk, not once per query.
-  constexpr int QC = 4;
   for (int i0 = 0; i0 < p.Lq; i0 += QC) {
     float qv[QC][4], o[QC][4], mx[QC], sum[QC];
 #pragma unroll
@@ -434,7 +436,12 @@ extern "C" int aurora_hip_perceiver_attention_ex(const void* q, int64_t q_col_st
   PercArgs p{q, q_col_stride, kv, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads, pair_guard, pair_limit};
   const int64_t items = (int64_t)B * cols_per_b * heads * (head_dim / 4);   // one lane per 4 features of a head
   const dim3 grid(blocks_for(items, 256)), block(256);
-#define AURORA_PERC(TT, HDIM) hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM>), grid, block, 0, as_stream(stream), p)
+#define AURORA_PERC(TT, HDIM)                                                                                              \
+  do {                                                                                                                   \
+    if (Lq % 3 == 0 && Lq <= 6) hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM, 3>), grid, block, 0, as_stream(stream), p); \
+    else if (Lq > 8 && HDIM <= 64) hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM, 7>), grid, block, 0, as_stream(stream), p); \
+    else hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM, 4>), grid, block, 0, as_stream(stream), p);              \
+  } while (0)
   if (dtype == AURORA_F32) {
     switch (head_dim) {
       case 16: AURORA_PERC(float, 16); break;
