@@ -1661,11 +1661,6 @@ namespace {
 // ticket per tile (zero on entry, left zero).
 struct SplitWs { float* slabs; int64_t slab_bytes; int32_t* tickets; int n_tickets; int split; };
 
-// AURORA_GEMM_SPLIT (read once): forces a K split for A/B runs (0 = never, unset = the rule below).
-int split_override() {
-  static const int v = [] { const char* e = getenv("AURORA_GEMM_SPLIT"); return e ? atoi(e) : -1; }();
-  return v;
-}
 
 // K split of a plain bf16 linear on 256 x 256 tiles (1 = none).  Only launches that leave most of the chip idle and
 // have K to spare: tiles * split <= CUs (one round), >= 64 K-steps (K = 2048) per slice -- below that the slab round trip
@@ -1675,8 +1670,6 @@ int choose_split(int64_t M, int N, int K) {
   const int64_t tiles = ((M + BM2 - 1) / BM2) * (N / BN2), cus = device_cus();
   const int kt = K / 32;
   int s = (int)std::min<int64_t>(std::min<int64_t>(8, cus / tiles), kt / 64);
-  const int forced = split_override();
-  if (forced >= 0) s = std::min<int>(forced, kt / 4);
   return s < 1 ? 1 : s;
 }
 }  // namespace

@@ -300,8 +300,9 @@ static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const f
     const dim3 grid(row_blocks(M)), block(256);
     // few rows per CU (a latitude band's stages, the coarse stage of the un-sharded step): the latency chain of a row
     // bounds the launch, and the variant that requests the residual row up front halves it
-    static const int pre_env = [] { const char* e = getenv("AURORA_LN_PREFETCH"); return e ? atoi(e) : -1; }();
-    const bool pre = res != nullptr && (pre_env >= 0 ? pre_env != 0 : M <= (int64_t)96 * device_cus());
+    // (A/B inside the step, profiles/r04_ab_gn_lnprefetch_instep.log: forced on everywhere LayerNorm 11.2 -> 11.4 ms per
+    // un-sharded step -- twice the registers halve the waves of the big launches --, on a rank of eight 3.05 -> 2.86 ms)
+    const bool pre = res != nullptr && M <= (int64_t)96 * device_cus();
     if (pre) {
       if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 1, true>), grid, block, 0, as_stream(stream), p);
       else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 2, true>), grid, block, 0, as_stream(stream), p);

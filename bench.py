@@ -54,6 +54,26 @@ FLOP_PER_STEP = 96.8e12
 ALGO_BYTES_PER_GEMM_LAUNCH = 530.5e6
 
 
+def attention_moved_fraction(cfg, Hp: int, Wp: int) -> float:
+    """(bytes the window-attention launches of a step really move) / (bytes the contract's figure counts).  The contract
+     prices a block at 4 * L_pad * D * 2 B with L_pad the window-PADDED token count; padded positions
+    are never read or written (their q = k = v is the bias).  0.25 degree: stage 2 is 16,200 tokens padded to 18,432."""
+    import math
+
+    n = len(cfg.encoder_depths)
+    wc, wh, ww = cfg.window_size
+    moved = padded = 0.0
+    c, h, w = cfg.latent_levels, Hp, Wp
+    for i in range(n):
+        blocks = cfg.encoder_depths[i] + cfg.decoder_depths[n - 1 - i]
+        d = cfg.embed_dim << i
+        pc, ph, pw = (math.ceil(x / min(ws, x)) * min(ws, x) for x, ws in ((c, wc), (h, wh), (w, ww)))
+        moved += blocks * c * h * w * d
+        padded += blocks * pc * ph * pw * d
+        h, w = (h + 1) // 2, (w + 1) // 2
+    return moved / padded
+
+
 def synthetic_batch(cfg, H, W, seed, device, levels=LEVELS):
     from aurora_amd import Batch, Metadata, normalisation as nz
 
@@ -442,6 +462,9 @@ def main() -> None:
                                         "ms_per_step": (g["ms"] + f["ms"]) / per},
                 "attention": {"kernel": "window_attention_bf16", "bound": "hbm", "achieved": attn_gbs,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": attn_gbs / PEAK_HBM_GBS,
+                              # the same with the bytes really moved (padded window positions are never touched)
+                              "frac_moved_bytes": attn_gbs / PEAK_HBM_GBS * attention_moved_fraction(
+                                  model.config, (GH - GH % model.patch_size) // model.patch_size, GW // model.patch_size),
                               "launches_per_step": a["launches"] / per, "ms_per_step": a["ms"] / per},
             },
             "step_tflops": FLOP_PER_STEP / (ms_per_step * 1e-3) / 1e12 if (GH, GW) == (721, 1440) else None,

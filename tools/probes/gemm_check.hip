@@ -141,8 +141,7 @@ int main(int argc, char** argv) {
   HIP_OK(hipMalloc(&tickets, 4096 * 4));
   HIP_OK(hipMemset(tickets, 0, 4096 * 4));
   HIP_OK(hipMalloc(&err, 4));
-  printf("# AURORA_GEMM_SPLIT=%s CHECK_SPLIT=%d ws=%d\n", getenv("AURORA_GEMM_SPLIT") ? getenv("AURORA_GEMM_SPLIT") : "-", forced_split,
-         (int)use_ws);
+  printf("# CHECK_SPLIT=%d ws=%d\n", forced_split, (int)use_ws);
   int bad = 0;
   for (const auto& set : sets) {
     double tot_us = 0, tot_fl = 0;
