@@ -302,7 +302,7 @@ static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const f
     // bounds the launch, and the variant that requests the residual row up front halves it
     // (A/B inside the step, profiles/r04_ab_gn_lnprefetch_instep.log: forced on everywhere LayerNorm 11.2 -> 11.4 ms per
     // un-sharded step -- twice the registers halve the waves of the big launches --, on a rank of eight 3.05 -> 2.86 ms)
-    const bool pre = res != nullptr && M <= (int64_t)96 * device_cus();
+    const bool pre = res != nullptr && M <= (int64_t)40 * device_cus();   // (16,200 rows, the un-sharded stage 2: 74.5 -> 79.0 us with it)
     if (pre) {
       if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 1, true>), grid, block, 0, as_stream(stream), p);
       else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 2, true>), grid, block, 0, as_stream(stream), p);
