@@ -90,3 +90,12 @@ def test_constants_and_new_argument_contracts_match_the_header(built):
     assert L.aurora_hip_layernorm_split(16, 48, None, None, None, 0, 0, 0, None, 0, 16, 48, 4, 48, 1e-5, None) == -1
     assert L.aurora_hip_split_f16(16, 48, 16, 48, 4, 48, 1.0, None) == -1 and b"32" in err()
     assert L.aurora_hip_perceiver_attention_ex(16, 0, 16, 16, 1, 4, 4, 1, 3, 3, 3, 16, 1, 16, 1.0, None) == -1
+    # round 4 -- split-K with lent scratch: the plan is host arithmetic (the per-rank shapes of an 8-way band at the coarsest
+    # stage want three K-slices of their 72 tiles, the un-sharded shapes none), the scratch must be 16-byte aligned
+    assert L.aurora_hip_linear_workspace(2160, 2048, 8192, shim.BF16) == 72 * 3 * 256 * 256 * 4
+    assert L.aurora_hip_linear_workspace(2160, 2048, 2048, shim.BF16) == 0      # a slice would keep < 64 K-steps
+    assert L.aurora_hip_linear_workspace(16200, 2048, 8192, shim.BF16) == 0     # 512 tiles: nothing idles
+    assert L.aurora_hip_linear_workspace(2160, 2048, 8192, shim.F32) == 0       # bf16 only
+    assert L.aurora_hip_linear_ws(16, 8192, 16, 8192, None, 16, 2048, None, 0, None, 0, 2160, 2048, 8192, shim.BF16, 0,
+                                  8, 1 << 26, 16, 4096, 0, None) == -1 and b"workspace" in err()
+    assert L.aurora_hip_zero_words(None, 4, None) == -1 and L.aurora_hip_zero_words(16, 65, None) == -1
