@@ -1537,6 +1537,21 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
   if (wm == 0) __builtin_amdgcn_s_barrier();   // the early half waits for the late half's last phase: the ring is dead
   asm volatile("" ::: "memory");
 
+  // The residual rows of the first two 16-row passes are requested NOW, before bias / rounding / the two statistics passes:
+  // nothing they need depends on the product, and the ~3 us of statistics hide their HBM round trip.
+  const int L = lane & 31, half = lane >> 5;
+  const int col = wn * 128 + 4 * L;
+  f32x4 xr[3][8];
+  auto fetch_x = [&](int fm, f32x4 (&dst)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int64_t m = m0 + wm * 64 + 16 * fm + 2 * j + half;
+      m = m < p.M ? m : p.M - 1;
+      dst[j] = *reinterpret_cast<const f32x4*>(p.x_in + m * p.ldx + col);
+    }
+  };
+  fetch_x(0, xr[0]);
+  fetch_x(1, xr[1]);
   // ---- bias, rounding to bf16 ----
   const int nb = wn * 128 + 32 * g;
 #pragma unroll
@@ -1592,29 +1607,20 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
   //      c(r) = r ^ 2 (r >> 2): conflict-free for the b128 writes (a lane writes pieces 8g..8g+7 of row i16) and for the
   //      row-major b128 reads (two rows per instruction) under gfx950's 16-lane service groups ----
   char* const mine = smem + wave * 8192;
-  const int L = lane & 31, half = lane >> 5;
-  const int col = wn * 128 + 4 * L;
   f32x4 gn = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.gain) gn = *reinterpret_cast<const f32x4*>(p.gain + col);
   if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
   const int cw = (i16 ^ ((i16 >> 2) << 1)) & 31;
-  // The residual rows of a 16-row pass are fetched one pass ahead, all eight loads of a lane at once: x_out may alias
-  // x_in, so a load written behind the previous row's store would have to wait for it -- 32 exposed round trips per tile.
-  f32x4 xr[2][8];
-  auto fetch_x = [&](int fm, f32x4 (&dst)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int64_t m = m0 + wm * 64 + 16 * fm + 2 * j + half;
-      m = m < p.M ? m : p.M - 1;
-      dst[j] = *reinterpret_cast<const f32x4*>(p.x_in + m * p.ldx + col);
-    }
-  };
-  fetch_x(0, xr[0]);
+  // The residual rows of a 16-row pass are fetched ahead of it, all eight loads of a lane at once: x_out may alias x_in, so
+  // a load written behind the previous row's store would have to wait for it -- 32 exposed round trips per tile.  TWO
+  // passes ahead (round 4; one before): the 32 accumulator registers a pass has parked in LDS are free from there on, so
+  // the third buffer costs no register the main loop needs, and the epilogue is a latency chain on 8 waves -- the bytes
+  // in flight are what its bandwidth is made of.
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) {
-    if (fm + 1 < 4) fetch_x(fm + 1, xr[(fm + 1) & 1]);
 #pragma unroll
     for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(mine + i16 * 512 + (((8 * g + q) ^ cw) << 4)) = acc[q][fm];
+    if (fm + 2 < 4) fetch_x(fm + 2, xr[(fm + 2) % 3]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r16 = 2 * j + half;
@@ -1623,7 +1629,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
       const float mu = st_mr[(16 * fm + r16) * 2], rs = st_mr[(16 * fm + r16) * 2 + 1];
       const int64_t m = m0 + wm * 64 + 16 * fm + r16;
       if (m < p.M) {
-        const f32x4 x = xr[fm & 1][j];
+        const f32x4 x = xr[fm % 3][j];
         f32x4 o;
         o.x = fmaf((v.x - mu) * rs, gn.x, sh.x) + x.x;
         o.y = fmaf((v.y - mu) * rs, gn.y, sh.y) + x.y;
