@@ -17,7 +17,8 @@ struct CtxGuard { const float* word; float a, c, limit_kv; bool pairs; };
 // b*kv_bstride + j*kv_lstride + l.  First layer: latents (and so q) are shared by every column.  Returns (B*cols*Lq, D).
 float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, int64_t ctx_rows, int ctx_dim, const float* q0,
                  const float* latents0, int B, int64_t cols, int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads,
-                 float eps, size_t& out_mark, const CtxGuard* cg = nullptr, bool out_pairs = false, int own_word = 0) {
+                 float eps, size_t& out_mark, const CtxGuard* cg = nullptr, bool out_pairs = false, int own_word = 0,
+                 bool scan_ctx = true) {
   const int64_t n_rows = (int64_t)B * cols * Lq;
   // The context is as unbounded as the model inputs, so the linears that read it, or averages of its value projection,
   // pick their operand split on the device: from max |ctx|, measured here, or from the bound the caller derived from a
@@ -25,9 +26,9 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
   const float* ctx_max = cg ? cg->word : m.ctx_max.f() + own_word;
   const float g_a = cg ? cg->a : 1.0f, g_c = cg ? cg->c : 0.0f;
   const bool ctx_pairs = cg && cg->pairs;
-  // (the words were cleared at the start of the step; the two decoder Perceivers of a `separate_perceiver` model scan the
-  // same context into the same word)
-  if (!cg)
+  // (the words were cleared at the start of the step; of the two decoder Perceivers of a `separate_perceiver` model only the
+  // first scans their common context: `scan_ctx`)
+  if (!cg && scan_ctx)
     timed(m, L.stream, K_ABSMAX, 0.0, [&] { return aurora_hip_absmax_fold(ctx, ctx_rows * ctx_dim, m.ctx_max.f() + own_word, L.stream); });
   float* lat = nullptr;
   for (size_t i = 0; i < rs.layers.size(); ++i) {
@@ -627,7 +628,8 @@ void run_step(Model& m, const StepIO& s, void* stream) {
       const bool two_term = hg.n_pad > 0 && last_pairs && (gi == 0 ? m.dec_out_bound : m.dec_out_bound_alt) < F16_SAFE;
       size_t rs_mark = 0;
       float* lat = resampler(m, L, rs, ctx, (int64_t)B * (Cl - 1) * Lp, D2, groups[gi].q, m.dec_queries.f(), B, Lp,
-                             (int64_t)(Cl - 1) * Lp, Lp, C, Cl - 1, m.perceiver_heads, m.ln_eps, rs_mark, nullptr, two_term, 3);
+                             (int64_t)(Cl - 1) * Lp, Lp, C, Cl - 1, m.perceiver_heads, m.ln_eps, rs_mark, nullptr, two_term, 3,
+                             /*scan_ctx=*/gi == 0 || m.head_main.names.empty());
       const int n_a = two_term ? hg.n_pad : (int)hg.names.size() * PP, ld_a = round_up(n_a, 4);
       const float* hw = two_term ? (const float*)hg.ws.p : hg.w.f();
       const float* hb = two_term ? hg.bs.f() : hg.b.f();
