@@ -1291,3 +1291,12 @@ extern "C" int aurora_hip_abi_sizes(int32_t* out, int capacity) {
 }
 
 extern "C" int64_t aurora_hip_workspace_bytes(const aurora_hip_model* m) { return m ? (int64_t)m->arena.cap : 0; }
+
+extern "C" int aurora_hip_guard_words(const aurora_hip_model* m, float out[4], void* stream) {
+  GUARDED({
+    REQUIRE(m && out && m->ctx_max.p, "guard_words: bad arguments");
+    static_assert(AURORA_F16_SAFE_RANGE == F16_SAFE, "the header's constant is the step's");
+    hip_ok(hipMemcpyAsync(out, m->ctx_max.p, 4 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream), "guard_words");
+    hip_ok(hipStreamSynchronize((hipStream_t)stream), "guard_words");
+  })
+}

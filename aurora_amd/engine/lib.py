@@ -620,6 +620,7 @@ _SIGNATURES.update({
     "aurora_hip_set_time": (c_int, [c_void_p, _PD, c_int, c_void_p]),
     "aurora_hip_step": (c_int, [c_void_p, ctypes.POINTER(HipStepIO), c_void_p]),
     "aurora_hip_workspace_bytes": (c_int64, [c_void_p]),
+    "aurora_hip_guard_words": (c_int, [c_void_p, ctypes.POINTER(c_float), c_void_p]),
     "aurora_hip_abi_sizes": (c_int, [ctypes.POINTER(c_int32), c_int]),
     "aurora_hip_generation": (c_int64, [c_void_p]),
     "aurora_hip_output_vars": (c_int, [c_void_p, _PS, c_int]),

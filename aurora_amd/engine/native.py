@@ -361,6 +361,13 @@ class NativeModel:
     def workspace_bytes(self) -> int:
         return int(lib.load().aurora_hip_workspace_bytes(self._h))
 
+    def guard_words(self) -> tuple[float, float, float, float]:
+        """The device-side range words of the last step (include/aurora_hip.h: aurora_hip_guard_words): max |encoder
+        context| (0 inside the guarded chain), max |normalised atmospheric / surface input|, max |decoder context|."""
+        out = (ctypes.c_float * 4)()
+        lib._check(lib.load().aurora_hip_guard_words(self._h, out, lib._stream()))
+        return tuple(float(v) for v in out)
+
     def generation(self) -> int:
         """Changes whenever the handle re-allocates device memory a captured hipGraph may point at."""
         return int(lib.load().aurora_hip_generation(self._h))

@@ -445,6 +445,13 @@ int aurora_hip_pos_scale_encoding(const double* lat, const double* lon, int n_la
 int aurora_hip_set_time(aurora_hip_model* model, const double* time_hours, int B, void* stream);
 int aurora_hip_step(aurora_hip_model* model, const aurora_hip_step_io* io, void* stream);
 int64_t aurora_hip_workspace_bytes(const aurora_hip_model* model);
+/* Which fp32 path did the last step take?  The large fp32 linears of encoder and decoder pick their operand split on the
+ * DEVICE, from guard words the step leaves behind (aurora_hip_linear_ex): out[0] max |encoder context| (only when the encoder
+ * is not part of the guarded chain, else 0), out[1] / out[2] max |normalised atmospheric / surface input| (folded in by
+ * patchify), out[3] max |decoder context|.  A word below AURORA_F16_SAFE_RANGE (after the layer's own scaling, see
+ * DESIGN.md 3) means two fp16 terms, above it three bf16 terms -- same accuracy, different speed.  Synchronises `stream`. */
+#define AURORA_F16_SAFE_RANGE 16384.0f
+int aurora_hip_guard_words(const aurora_hip_model* model, float out[4], void* stream);
 /* Counts the re-allocations of device memory that enqueued work points at: the workspace (it grows with the first step of
  * a larger batch / history / grid), the time buffers (a larger batch), the grid tables (aurora_hip_precompute).  A hipGraph
  * captured from aurora_hip_step is valid for as long as this number does not change. */

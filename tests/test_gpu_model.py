@@ -109,6 +109,69 @@ def test_bf16_engine_within_autocast_tolerance(name):
         assert errs[k] < 3 * base[k] + 1e-3, (k, errs[k], base[k])
 
 
+def test_guard_words_say_which_fp32_path_a_step_took():
+    """The large fp32 linears of encoder and decoder pick two fp16 terms or three bf16 terms on the DEVICE, from range words the
+    step leaves behind; `aurora_hip_guard_words` hands them to the host afterwards.  Word 1 / 2 are max |normalised input| of
+    the atmospheric / surface patch embedding exactly (patchify folds them in, no separate pass); raw `randn` fields -- the
+    upstream README example -- push them past fp16's safe range, and the step takes the three-term kernels."""
+    from datetime import datetime
+
+    model = aurora_amd.AuroraSmallPretrained()      # (the README model: its patch embeddings run as guarded chains)
+    torch.manual_seed(0)
+    for p in model.parameters():
+        if p.abs().sum() == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    model = model.to("cuda").eval()
+    levels = (100, 250, 500, 850)
+    g = torch.Generator().manual_seed(3)
+    batch = Batch(
+        surf_vars={k: torch.randn(1, 2, 17, 32, generator=g) for k in ("2t", "10u", "10v", "msl")},
+        static_vars={k: torch.randn(17, 32, generator=g) for k in ("lsm", "z", "slt")},
+        atmos_vars={k: torch.randn(1, 2, 4, 17, 32, generator=g) for k in ("z", "u", "v", "t", "q")},
+        metadata=Metadata(lat=torch.linspace(90, -90, 17), lon=torch.linspace(0, 360, 32 + 1)[:-1],
+                          time=(datetime(2020, 6, 1, 12, 0),), atmos_levels=levels),
+    )
+    with torch.inference_mode():
+        model.forward(batch)
+    w = model.engine().native.guard_words()
+    batch = batch.crop(model.patch_size)
+
+    def norm_max(d, affine):
+        m = 0.0
+        for k, v in d.items():
+            loc, scale = affine(k)
+            loc_t, scale_t = torch.tensor(loc, dtype=torch.float32), torch.tensor(scale, dtype=torch.float32)
+            shape = (-1, 1, 1) if loc_t.numel() > 1 else ()
+            m = max(m, float(((v.float().cpu() - loc_t.reshape(shape)) / scale_t.reshape(shape)).abs().max()))
+        return m
+
+    atmos = norm_max(batch.atmos_vars, lambda k: normalisation.atmos_affine(k, levels))
+    surf = max(norm_max(batch.surf_vars, normalisation.surf_affine), norm_max(batch.static_vars, normalisation.surf_affine))
+    assert abs(w[1] - atmos) <= 2e-6 * atmos and abs(w[2] - surf) <= 2e-6 * surf, (w, atmos, surf)
+    assert 0.0 < w[3] < float("inf") and w[0] == 0.0     # the encoder ran as one guarded chain: its own word stays clear
+    assert w[1] > 16384.0                                 # raw randn fields: (x - loc) / scale of q is ~1e6 -> three bf16 terms
+
+    # the same fields in physical units (randn in NORMALISED space): inside fp16's range -> two fp16 terms
+    def physical(d, affine):
+        out = {}
+        for k, v in d.items():
+            loc, scale = affine(k)
+            loc_t, scale_t = torch.tensor(loc, dtype=torch.float32), torch.tensor(scale, dtype=torch.float32)
+            shape = (-1, 1, 1) if loc_t.numel() > 1 else ()
+            out[k] = v * scale_t.reshape(shape) + loc_t.reshape(shape)
+        return out
+
+    phys = dataclasses.replace(batch, surf_vars=physical(batch.surf_vars, normalisation.surf_affine),
+                               static_vars=physical(batch.static_vars, normalisation.surf_affine),
+                               atmos_vars=physical(batch.atmos_vars, lambda k: normalisation.atmos_affine(k, levels)))
+    with torch.inference_mode():
+        pred = model.forward(phys)
+    w2 = model.engine().native.guard_words()
+    want = max(float(v.abs().max()) for v in batch.atmos_vars.values())
+    assert abs(w2[1] - want) <= 1e-3 * want and w2[1] < 16384.0 and w2[2] < 16384.0, (w2, want)
+    assert all(torch.isfinite(v).all() for v in pred.atmos_vars.values())
+
+
 def test_readme_example_runs_unchanged():
     """README.md:77-102 upstream, with `aurora` -> `aurora_amd` and the model on the GPU."""
     from datetime import datetime
