@@ -60,44 +60,49 @@ __device__ __forceinline__ float patch_transform(float z, const PatchVar& d) {
   return z;
 }
 
-// Patch size 4, fp32, every piece 16-byte aligned (the 0.25-degree models):
-__global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
-  typedef float T;
-  // item = (row, q) with q = (v*T + t)*P + i fastest: neighbouring threads fill one output row.
-  const int L = p.Hp * p.Wp;
-  const int64_t rows = (int64_t)p.n_lvl * p.B * L;
-  const int q_per_row = p.n_vars * p.T * p.P;
-  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (item >= rows * q_per_row) {   // (whole waves of the last block, or its last wave's tail: they still join the reduction)
-    if (p.absmax) fold_absmax(p.absmax, 0.f);
-    return;
+// Patch size 4, fp32, every piece 16-byte aligned (the 0.25-degree models).  A workgroup owns a run of 8 * PATCH4_GROUPS
+// patches of one patch row at one level; lane = (piece q = (variable, time, image row i) of the output row, patch s of 8):
+// the eight lanes of a q read 128 contiguous bytes of one image row of one field, the eight q of an s write 128 contiguous
+// bytes of one output row -- whole cache lines on both sides, the position decoded once per PATCH4_GROUPS pieces.  (The
+// first form, one thread per piece in output order, decoded a flat 64-bit index with six 64-bit divisions: ~700 VALU
+// instructions per 16 bytes, 0.27 ms per launch where the bytes take 0.09.)
+constexpr int PATCH4_GROUPS = 4;
+
+__global__ __launch_bounds__(1024) void patchify_kernel(const PatchArgs p) {
+  // grid: x = run of 8 * PATCH4_GROUPS patches, y = patch row, z = (level, batch); blockDim = 8 * pieces per row, rounded up
+  const int q_per_row = p.n_vars * p.T * 4;
+  const int q = (int)(threadIdx.x >> 3);
+  float m = 0.f;
+  if (q < q_per_row) {
+    const int i = q & 3, vt = q >> 2;
+    const int v = vt / p.T, t = vt - v * p.T;
+    const unsigned hp = blockIdx.y;
+    const unsigned c = blockIdx.z / (unsigned)p.B, b = blockIdx.z - c * (unsigned)p.B;
+    const int wp = (int)(blockIdx.x * (8u * PATCH4_GROUPS) + (threadIdx.x & 7u));
+    const PatchVar& d = p.v[v];
+    const float loc = d.loc[c], inv = d.inv_scale[c];
+    const float* src = d.src + b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * 4 + i) * d.sh + (int64_t)wp * 4;   // (stride_w == 1)
+    const int64_t row = ((int64_t)blockIdx.z * p.Hp + hp) * p.Wp + wp;   // rows are (level, batch, patch)
+    float* out_row = reinterpret_cast<float*>(p.out) + row * p.Kpad;
+    float* dst = out_row + p.k_offset + q * 4;
+    // the K padding of a row is zeroed by the thread of its last piece, if this call ends the row
+    const bool pads = q == q_per_row - 1 && p.k_offset + q_per_row * 4 == p.K_total;
+    f32x4 z[PATCH4_GROUPS];
+#pragma unroll
+    for (int g = 0; g < PATCH4_GROUPS; ++g)
+      if (wp + 8 * g < p.Wp) z[g] = *reinterpret_cast<const f32x4*>(src + 32 * g);
+#pragma unroll
+    for (int g = 0; g < PATCH4_GROUPS; ++g)
+      if (wp + 8 * g < p.Wp) {
+        const f32x4 r4 = f32x4{patch_transform((z[g].x - loc) * inv, d), patch_transform((z[g].y - loc) * inv, d),
+                               patch_transform((z[g].z - loc) * inv, d), patch_transform((z[g].w - loc) * inv, d)};
+        *reinterpret_cast<f32x4*>(dst + 8 * g * p.Kpad) = r4;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(r4.x), fabsf(r4.y)), fmaxf(fabsf(r4.z), fabsf(r4.w))));
+        if (pads)
+          for (int64_t k = p.K_total; k < p.Kpad; ++k) out_row[8 * g * p.Kpad + k] = 0.f;
+      }
   }
-  const int64_t row = item / q_per_row;
-  const int q = (int)(item - row * q_per_row);
-  const int i = q % p.P;
-  const int vt = q / p.P;
-  const int t = vt % p.T, v = vt / p.T;
-  const int l = (int)(row % L);
-  const int64_t cb = row / L;  // rows are (level, batch, patch)
-  const int b = (int)(cb % p.B), c = (int)(cb / p.B);
-  const int hp = l / p.Wp, wp = l - hp * p.Wp;
-  const PatchVar& d = p.v[v];
-  const float loc = d.loc[c], inv = d.inv_scale[c];
-  const float* src = d.src + b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)(wp * p.P) * d.sw;
-  T* dst = reinterpret_cast<T*>(p.out) + row * p.Kpad + p.k_offset + (int64_t)vt * p.P * p.P + i * p.P;
-  {
-    // patch size 4, fp32 operand, aligned (checked by the launcher): one 16-byte load and one 16-byte store per thread
-    const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
-    const f32x4 r4 = f32x4{patch_transform((s4.x - loc) * inv, d), patch_transform((s4.y - loc) * inv, d),
-                           patch_transform((s4.z - loc) * inv, d), patch_transform((s4.w - loc) * inv, d)};
-    *reinterpret_cast<f32x4*>(dst) = r4;
-    if (p.absmax) fold_absmax(p.absmax, fmaxf(fmaxf(fabsf(r4.x), fabsf(r4.y)), fmaxf(fabsf(r4.z), fabsf(r4.w))));
-  }
-  // zero the K padding of this row (done by the threads of the last variable's last piece)
-  if (q == q_per_row - 1 && p.k_offset + q_per_row * p.P == p.K_total) {
-    T* pad = reinterpret_cast<T*>(p.out) + row * p.Kpad;
-    for (int64_t k = p.K_total; k < p.Kpad; ++k) elem<T>::store(pad + k, 0.f);
-  }
+  if (p.absmax) fold_absmax(p.absmax, m);
 }
 
 // Any patch size (10 at 0.1 degree, 3 for the air-pollution model): one thread per OUTPUT element, consecutive threads on
@@ -110,38 +115,54 @@ __global__ __launch_bounds__(256) void patchify_kernel(const PatchArgs p) {
 // LDS, then writes each patch's columns as one contiguous piece through a column -> LDS-word table) measured SLOWER on both
 // grids, 5.5 vs 4.4 ms at 0.1 degree and 2.2 vs 1.8 ms at 0.4 degree, with eight loads in flight per lane slower still: the
 // two phases of a workgroup do not overlap and 48 KiB of staging leaves three workgroups per CU to hide them.
+// What bounded that form was neither: ~200 VALU instructions per 4-byte element (five 32-bit divisions to decode the
+// column, a wave reduction for the range word) -- 14 M wave passes of 200 x 4 cycles are the 4.4 ms.  A thread now decodes
+// its column ONCE and walks PATCH_SPAN patches along the latitude circle with it (source += P pixels, destination += one
+// row): ~12 instructions per element, PATCH_SPAN independent loads in flight, one range-word reduction per thread.
+constexpr int PATCH_SPAN = 16;   // 16 patches x 10 pixels = 640 B of every image row: whole cache lines at 0.1 degree
+
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_cols_kernel(const PatchArgs p, const int k_end, const int chunks) {
-  // grid: x = (patch column, 256-column chunk of the row), y = patch row, z = (level, batch) -- 32-bit index arithmetic
-  // only (a flat 64-bit item index cost six 64-bit divisions per element: the kernel was bound by them, not by memory).
-  // k runs over this call's columns [k_offset, k_end): its variables, plus the zero padding if the call ends at K_total.
+  // grid: x = (group of PATCH_SPAN patch columns, 256-column chunk of the row), y = patch row, z = (level, batch) -- 32-bit
+  // index arithmetic only.  k runs over this call's columns [k_offset, k_end): its variables, plus the zero padding if the
+  // call ends at K_total.
   const int n_k = k_end - p.k_offset;
-  const unsigned wp = blockIdx.x / (unsigned)chunks, chunk = blockIdx.x - wp * (unsigned)chunks;
+  const unsigned g = blockIdx.x / (unsigned)chunks, chunk = blockIdx.x - g * (unsigned)chunks;
   const int kk = (int)(chunk * 256u + threadIdx.x);
-  if (kk >= n_k) {
-    if (p.absmax) fold_absmax(p.absmax, 0.f);
-    return;
+  const unsigned wp0 = g * (unsigned)PATCH_SPAN;
+  const int n = min(PATCH_SPAN, p.Wp - (int)wp0);
+  float m = 0.f;
+  if (kk < n_k) {
+    const unsigned hp = blockIdx.y;
+    const unsigned c = blockIdx.z / (unsigned)p.B, b = blockIdx.z - c * (unsigned)p.B;
+    const int64_t row = ((int64_t)blockIdx.z * p.Hp + hp) * p.Wp + wp0;   // rows are (level, batch, patch)
+    T* dst = reinterpret_cast<T*>(p.out) + row * p.Kpad + p.k_offset + kk;
+    const unsigned PP = (unsigned)(p.P * p.P);
+    const unsigned vt = (unsigned)kk / PP;
+    if ((int)vt >= p.n_vars * p.T) {   // K padding
+      for (int s = 0; s < n; ++s) elem<T>::store(dst + s * p.Kpad, 0.f);
+    } else {
+      const unsigned ij = (unsigned)kk - vt * PP;
+      const unsigned i = ij / (unsigned)p.P, j = ij - i * (unsigned)p.P;
+      const unsigned v = vt / (unsigned)p.T, t = vt - v * (unsigned)p.T;
+      const PatchVar& d = p.v[v];
+      const float* src = d.src + b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)(wp0 * p.P + j) * d.sw;
+      const int64_t step = (int64_t)p.P * d.sw;
+      const float loc = d.loc[c], inv = d.inv_scale[c];
+      float z[PATCH_SPAN];
+#pragma unroll
+      for (int s = 0; s < PATCH_SPAN; ++s)
+        if (s < n) z[s] = src[s * step];
+#pragma unroll
+      for (int s = 0; s < PATCH_SPAN; ++s)
+        if (s < n) {
+          const float r = patch_transform((z[s] - loc) * inv, d);
+          elem<T>::store(dst + s * p.Kpad, r);
+          m = fmaxf(m, fabsf(r));
+        }
+    }
   }
-  const unsigned hp = blockIdx.y;
-  const unsigned c = blockIdx.z / (unsigned)p.B, b = blockIdx.z - c * (unsigned)p.B;
-  const int64_t row = ((int64_t)blockIdx.z * p.Hp + hp) * p.Wp + wp;   // rows are (level, batch, patch)
-  T* dst = reinterpret_cast<T*>(p.out) + row * p.Kpad + p.k_offset + kk;
-  const unsigned PP = (unsigned)(p.P * p.P);
-  const unsigned vt = (unsigned)kk / PP;
-  if ((int)vt >= p.n_vars * p.T) {   // K padding
-    elem<T>::store(dst, 0.f);
-    if (p.absmax) fold_absmax(p.absmax, 0.f);
-    return;
-  }
-  const unsigned ij = (unsigned)kk - vt * PP;
-  const unsigned i = ij / (unsigned)p.P, j = ij - i * (unsigned)p.P;
-  const unsigned v = vt / (unsigned)p.T, t = vt - v * (unsigned)p.T;
-  const PatchVar& d = p.v[v];
-  const float z = (d.src[b * d.sb + t * d.st + c * d.sc + (int64_t)(hp * p.P + i) * d.sh + (int64_t)(wp * p.P + j) * d.sw] - d.loc[c]) *
-                  d.inv_scale[c];
-  const float r = patch_transform(z, d);
-  elem<T>::store(dst, r);
-  if (p.absmax) fold_absmax(p.absmax, fabsf(r));
+  if (p.absmax) fold_absmax(p.absmax, m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,72 +316,89 @@ struct UnpatchArgs {
   int vec4;   // P == 4 and every source / destination piece is 16-byte aligned
 };
 
-// VEC = 4: patch size 4, aligned: a thread owns one patch row (16-byte pieces).  VEC = 1: any patch size: a thread owns one
-// PIXEL, consecutive threads on consecutive longitudes, so that every store of a wave writes 256 contiguous bytes of the
-// output field (the loads are runs of P head outputs per patch; the other image rows of the same patches read the rest of
-// those lines out of L2).
+// VEC = 4: patch size 4, every piece 16-byte aligned.  A workgroup owns a run of 8 * UNPATCH_GROUPS patches of one patch
+// row at one level; lane = (piece q = (variable, image row i) of the head row, patch s of 8): the eight lanes of a q write
+// 128 contiguous bytes of one image row of one field, the eight q of an s read 128 contiguous bytes of one head row --
+// whole cache lines on both sides.  (One thread per piece in (variable, ..., patch) order read a 16-byte piece per line and
+// instruction and came back for the rest of each line a variable later: the head outputs crossed the fabric up to eight
+// times, 0.38 ms per step where the bytes take 0.1, and six 64-bit divisions per thread did not help.)
+// VEC = 1: any patch size: a thread owns one pixel COLUMN of a patch row -- consecutive threads on consecutive longitudes,
+// so that every store of a wave writes 256 contiguous bytes of the output field -- and walks the P image rows of that
+// patch row with it (head outputs += P, field += one image row): its position is decoded once per P pixels, and the
+// P x P head outputs of a patch, one contiguous run, are used up by the same wave while they sit in L1.
+constexpr int UNPATCH_GROUPS = 4;
+
 template <int VEC>
-__global__ __launch_bounds__(256) void unpatchify_kernel(const UnpatchArgs p) {
+__global__ __launch_bounds__(VEC == 4 ? 1024 : 256) void unpatchify_kernel(const UnpatchArgs p) {
   int v, wp, j0, i, hp, c, b;
   if constexpr (VEC == 4) {
-    // item = (v, b, c, hp, i, wp), wp fastest: neighbouring threads write one output row.
-    const int64_t per_var = (int64_t)p.B * p.n_lvl * p.Hp * p.P * p.Wp;
-    const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= per_var * p.n_vars) return;
-    v = (int)(item / per_var);
-    int64_t r = item - (int64_t)v * per_var;
-    wp = (int)(r % p.Wp); r /= p.Wp;
-    j0 = 0;
-    i = (int)(r % p.P); r /= p.P;
-    hp = (int)(r % p.Hp); r /= p.Hp;
-    c = (int)(r % p.n_lvl);
-    b = (int)(r / p.n_lvl);
+    // grid: x = run of 8 * UNPATCH_GROUPS patches, y = patch row, z = (batch, level)
+    const int q = (int)(threadIdx.x >> 3);
+    if (q >= p.n_vars * 4) return;
+    v = q >> 2; i = q & 3; j0 = 0;
+    wp = (int)(blockIdx.x * (8u * UNPATCH_GROUPS) + (threadIdx.x & 7u));
+    hp = (int)blockIdx.y;
+    b = (int)(blockIdx.z / (unsigned)p.n_lvl); c = (int)(blockIdx.z - (unsigned)b * (unsigned)p.n_lvl);
   } else {
-    // grid: x = 256-pixel chunk of an image row, y = image row, z = (variable, batch, level): 32-bit index arithmetic only
+    // grid: x = 256-pixel chunk of an image row, y = patch row, z = (variable, batch, level): 32-bit index arithmetic only
     const unsigned x = blockIdx.x * 256u + threadIdx.x;
     if (x >= (unsigned)(p.Wp * p.P)) return;
     wp = (int)(x / (unsigned)p.P); j0 = (int)(x - (unsigned)wp * (unsigned)p.P);
-    hp = (int)(blockIdx.y / (unsigned)p.P); i = (int)(blockIdx.y - (unsigned)hp * (unsigned)p.P);
+    hp = (int)blockIdx.y; i = 0;
     const unsigned vb = blockIdx.z / (unsigned)p.n_lvl;
     c = (int)(blockIdx.z - vb * (unsigned)p.n_lvl);
     v = (int)(vb / (unsigned)p.B); b = (int)(vb - (unsigned)v * (unsigned)p.B);
   }
   const UnpatchVar& d = p.v[v];
   const int64_t L = (int64_t)p.Hp * p.Wp;
-  const float* row = p.y + (((int64_t)b * L + (int64_t)hp * p.Wp + wp) * p.n_lvl + c) * p.ldy + c * d.lvl_stride + i * p.P;
-  const float* src = row + d.col0;
   const int64_t W = (int64_t)p.Wp * p.P, H = (int64_t)p.Hp * p.P;
-  const int64_t hh = (int64_t)hp * p.P + i, ww = (int64_t)wp * p.P;
-  float* dst = d.dst + (((int64_t)b * p.n_lvl + c) * H + hh) * W + ww;
   const float loc = d.loc[c], sc = d.scale[c];
   const bool has_mod = d.mod_col0 >= 0;
-  const float* mod = row + (has_mod ? d.mod_col0 : 0);
-  const float* prev = has_mod ? d.prev + b * d.prev_sb + c * d.prev_sc + hh * d.prev_sh + ww : nullptr;
   const float inv = has_mod ? d.inv_scale[c] : 0.f;
   const bool cap1 = (d.clamp_max1_levels >> c) & 1u;
-  const float* cosp = d.angle_col0 >= 0 ? row + d.angle_col0 : nullptr;   // wave: col0 = sin head, this = cos head
-  const float* dens = d.dens_col0 >= 0 ? row + d.dens_col0 : nullptr;     // wave: density head
-  const float* maskp = dens ? d.mask + hh * d.mask_sh + ww : nullptr;     // raw water-body mask plane
-  auto finish = [&](float z, int j) -> float {
-    if (has_mod) z = z + (1.0f + mod[j]) * ((prev[j] - loc) * inv);
-    if (cap1) z = fminf(z, 1.0f);
-    if (d.clamp_min0) z = fmaxf(z, 0.f);
-    if (cosp) {  // direction from its sin / cos heads: rad2deg(atan2(sin, cos)) mod 360 in [0, 360)
-      z = atan2f(z, cosp[j]) * 57.29577951308232f;
-      z = fmodf(z, 360.0f);
-      if (z < 0.f) z += 360.0f;
+  // everything of patch column `wp` (image rows hp * P + i ...)
+  auto patch = [&](int wp) {
+    const float* row = p.y + (((int64_t)b * L + (int64_t)hp * p.Wp + wp) * p.n_lvl + c) * p.ldy + c * d.lvl_stride + i * p.P;
+    const float* src = row + d.col0;
+    const int64_t hh = (int64_t)hp * p.P + i, ww = (int64_t)wp * p.P;
+    float* dst = d.dst + (((int64_t)b * p.n_lvl + c) * H + hh) * W + ww;
+    const float* mod = row + (has_mod ? d.mod_col0 : 0);
+    const float* prev = has_mod ? d.prev + b * d.prev_sb + c * d.prev_sc + hh * d.prev_sh + ww : nullptr;
+    const float* cosp = d.angle_col0 >= 0 ? row + d.angle_col0 : nullptr;   // wave: col0 = sin head, this = cos head
+    const float* dens = d.dens_col0 >= 0 ? row + d.dens_col0 : nullptr;     // wave: density head
+    const float* maskp = dens ? d.mask + hh * d.mask_sh + ww : nullptr;     // raw water-body mask plane
+    // j indexes the head outputs; the fields' own rows are prev_sh / mask_sh apart, not P (VEC = 1 walks image rows)
+    auto finish = [&](float z, int j, int64_t prev_j, int64_t mask_j) -> float {
+      if (has_mod) z = z + (1.0f + mod[j]) * ((prev[prev_j] - loc) * inv);
+      if (cap1) z = fminf(z, 1.0f);
+      if (d.clamp_min0) z = fmaxf(z, 0.f);
+      if (cosp) {  // direction from its sin / cos heads: rad2deg(atan2(sin, cos)) mod 360 in [0, 360)
+        z = atan2f(z, cosp[j]) * 57.29577951308232f;
+        z = fmodf(z, 360.0f);
+        if (z < 0.f) z += 360.0f;
+      }
+      if (dens) {  // present only over water AND where sigmoid(density) >= 0.5 (aurora.py:924-930)
+        const bool water = maskp[mask_j] > d.mask_thresh;
+        z = (water && !(dens[j] < 0.f)) ? z : __int_as_float(0x7fc00000);
+      }
+      return z * sc + loc;
+    };
+    if constexpr (VEC == 4) {
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
+      *reinterpret_cast<f32x4*>(dst) = f32x4{finish(s4.x, 0, 0, 0), finish(s4.y, 1, 1, 1), finish(s4.z, 2, 2, 2), finish(s4.w, 3, 3, 3)};
+    } else {
+      for (int ii = 0; ii < p.P; ++ii) {
+        const int j = ii * p.P + j0;
+        dst[ii * W + j0] = finish(src[j], j, has_mod ? ii * d.prev_sh + j0 : 0, dens ? ii * d.mask_sh + j0 : 0);
+      }
     }
-    if (dens) {  // present only over water AND where sigmoid(density) >= 0.5 (aurora.py:924-930)
-      const bool water = maskp[j] > d.mask_thresh;
-      z = (water && !(dens[j] < 0.f)) ? z : __int_as_float(0x7fc00000);
-    }
-    return z * sc + loc;
   };
-  if constexpr (VEC == 4) {   // patch size 4 (every model but the high-res / air-pollution ones): 16-byte pieces
-    const f32x4 s4 = *reinterpret_cast<const f32x4*>(src);
-    *reinterpret_cast<f32x4*>(dst) = f32x4{finish(s4.x, 0), finish(s4.y, 1), finish(s4.z, 2), finish(s4.w, 3)};
+  if constexpr (VEC == 4) {
+#pragma unroll
+    for (int g = 0; g < UNPATCH_GROUPS; ++g)
+      if (wp + 8 * g < p.Wp) patch(wp + 8 * g);
   } else {
-    dst[j0] = finish(src[j0], j0);
+    patch(wp);
   }
 }
 
@@ -394,22 +432,25 @@ extern "C" int aurora_hip_patchify_absmax(const aurora_patch_var* desc, int n_va
   p.out = out; p.Kpad = Kpad; p.k_offset = k_offset; p.K_total = K_total;
   p.n_vars = n_vars; p.B = B; p.T = T; p.n_lvl = n_lvl; p.Hp = Hp; p.Wp = Wp; p.P = P;
   p.absmax = absmax;
-  const int64_t items = (int64_t)n_lvl * B * Hp * Wp * n_vars * T * P;
-  AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "patchify: bad problem size");
-  bool vec4 = P == 4 && dtype == AURORA_F32 && (uintptr_t)out % 16 == 0 && Kpad % 4 == 0 && k_offset % 4 == 0;
+  AURORA_CHECK_ARG(B > 0 && T > 0 && n_lvl > 0 && Hp > 0 && Wp > 0 && P > 0, "patchify: bad problem size");
+  bool vec4 = P == 4 && dtype == AURORA_F32 && (uintptr_t)out % 16 == 0 && Kpad % 4 == 0 && k_offset % 4 == 0 &&
+              n_vars * T * 32 <= 1024 && Hp <= 65535 && (int64_t)n_lvl * B <= 65535;
   for (int v = 0; v < n_vars && vec4; ++v) {
     const aurora_patch_var& s = desc[v];
     vec4 = s.stride_w == 1 && (uintptr_t)s.src % 16 == 0 && s.stride_b % 4 == 0 && s.stride_t % 4 == 0 && s.stride_c % 4 == 0 &&
            s.stride_h % 4 == 0;
   }
   if (vec4) {
-    hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+    const int run = 8 * PATCH4_GROUPS;
+    const dim3 grid((unsigned)((Wp + run - 1) / run), (unsigned)Hp, (unsigned)(n_lvl * B));
+    hipLaunchKernelGGL(patchify_kernel, grid, dim3((unsigned)((n_vars * T * 32 + 63) / 64 * 64)), 0, as_stream(stream), p);
   } else {
     const int k_end = k_offset + n_vars * T * P * P == K_total ? (int)Kpad : k_offset + n_vars * T * P * P;
     const int chunks = (k_end - k_offset + 255) / 256;
-    AURORA_CHECK_ARG((int64_t)Wp * chunks < ((int64_t)1 << 31) && Hp <= 65535 && (int64_t)n_lvl * B <= 65535,
+    const int groups = (Wp + PATCH_SPAN - 1) / PATCH_SPAN;
+    AURORA_CHECK_ARG((int64_t)groups * chunks < ((int64_t)1 << 31) && Hp <= 65535 && (int64_t)n_lvl * B <= 65535,
                      "patchify: grid too large (%d x %d patches, %d levels x %d)", Hp, Wp, n_lvl, B);
-    const dim3 grid((unsigned)(Wp * chunks), (unsigned)Hp, (unsigned)(n_lvl * B));
+    const dim3 grid((unsigned)(groups * chunks), (unsigned)Hp, (unsigned)(n_lvl * B));
     if (dtype == AURORA_F32)
       hipLaunchKernelGGL(patchify_cols_kernel<float>, grid, dim3(256), 0, as_stream(stream), p, k_end, chunks);
     else
@@ -499,13 +540,15 @@ extern "C" int aurora_hip_unpatchify(const float* y, int64_t ldy, const aurora_u
          (desc[v].angle_col0 < 0 || desc[v].angle_col0 % 4 == 0) &&
          (desc[v].dens_col0 < 0 || (desc[v].dens_col0 % 4 == 0 && (uintptr_t)desc[v].mask % 16 == 0 && desc[v].mask_sh % 4 == 0));
   p.vec4 = al ? 1 : 0;
-  const int64_t items = (int64_t)n_vars * B * n_lvl * Hp * P * Wp;
-  AURORA_CHECK_ARG(items > 0 && (items + 255) / 256 < ((int64_t)1 << 31), "unpatchify: bad problem size");
+  AURORA_CHECK_ARG(B > 0 && n_lvl > 0 && Hp > 0 && Wp > 0 && P > 0, "unpatchify: bad problem size");
   if (al) {
-    hipLaunchKernelGGL(unpatchify_kernel<4>, dim3(blocks_for(items, 256)), dim3(256), 0, as_stream(stream), p);
+    AURORA_CHECK_ARG(Hp <= 65535 && (int64_t)B * n_lvl <= 65535, "unpatchify: grid too large");
+    const int run = 8 * UNPATCH_GROUPS;
+    const dim3 grid((unsigned)((Wp + run - 1) / run), (unsigned)Hp, (unsigned)(B * n_lvl));
+    hipLaunchKernelGGL(unpatchify_kernel<4>, grid, dim3((unsigned)((n_vars * 32 + 63) / 64 * 64)), 0, as_stream(stream), p);
   } else {
-    AURORA_CHECK_ARG((int64_t)Hp * P <= 65535 && (int64_t)n_vars * B * n_lvl <= 65535, "unpatchify: grid too large");
-    const dim3 grid((unsigned)((Wp * P + 255) / 256), (unsigned)(Hp * P), (unsigned)(n_vars * B * n_lvl));
+    AURORA_CHECK_ARG(Hp <= 65535 && (int64_t)n_vars * B * n_lvl <= 65535, "unpatchify: grid too large");
+    const dim3 grid((unsigned)((Wp * P + 255) / 256), (unsigned)Hp, (unsigned)(n_vars * B * n_lvl));
     hipLaunchKernelGGL(unpatchify_kernel<1>, grid, dim3(256), 0, as_stream(stream), p);
   }
   return check_launch("unpatchify");

@@ -521,10 +521,10 @@ def test_merge_and_split(H, W, dtype):
 # ------------------------------------------------------------------------------------------
 # embed / unembed
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("P", [3, 4, 10])
-def test_patchify_matches_conv_unfold(P):
+@pytest.mark.parametrize("P,Wp", [(3, 7), (4, 7), (10, 7), (3, 37), (10, 32), (4, 37)])   # 37: two full spans of the any-P kernel and a ragged one
+def test_patchify_matches_conv_unfold(P, Wp):
     L = lib()
-    B, T, C, Hp, Wp, V = 2, 2, 3, 5, 7, 3
+    B, T, C, Hp, V = 2, 2, 3, 5, 3
     H, W = Hp * P, Wp * P
     x = rnd(B, T, V, C, H + 1, W, seed=1, scale=5.0).float()  # one extra latitude row (cropped view)
     static = rnd(H, W, seed=2).float()
@@ -542,7 +542,7 @@ def test_patchify_matches_conv_unfold(P):
         else:
             descs.append(L.PatchVar(sdv.data_ptr(), 0, 0, 0, W, 1, lo.data_ptr(), inv.data_ptr(), 0, 0.0, 0.0, 0.0))
     K = (V + 1) * T * P * P
-    Kpad = (K + 31) // 32 * 32
+    Kpad = (K + 31) // 32 * 32 + 32   # (always some K padding for the kernel to zero)
     out = torch.full((C * B * Hp * Wp, Kpad), float("nan"), device=DEV)
     word = torch.full((1,), 0.25, device=DEV)    # folded into, not overwritten
     L.patchify(descs, out, 0, K, B, T, C, Hp, Wp, P, absmax=word)
@@ -559,9 +559,10 @@ def test_patchify_matches_conv_unfold(P):
     assert (out[:, K:] == 0).all()
 
 
-def test_unpatchify_matches_oracle():
+@pytest.mark.parametrize("P,Wp", [(4, 6), (3, 6), (10, 6), (10, 29), (4, 67)])   # Wp * P past one 256-pixel block as well
+def test_unpatchify_matches_oracle(P, Wp):
     L = lib()
-    B, CA, Hp, Wp, P, V = 2, 3, 4, 6, 4, 3
+    B, CA, Hp, V = 2, 3, 4, 3
     H, W = Hp * P, Wp * P
     y = rnd(B * Hp * Wp * CA, V * P * P, seed=1).float()
     loc, sc = rnd(V, CA, seed=2).float(), (rnd(V, CA, seed=3).abs() + 0.5).float()

@@ -47,6 +47,16 @@ def timed_rollout(model, batch, steps, **kw):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def kinds(model, batch):
+    """ms per kernel family of ONE step (HIP events around every launch inside the handle)."""
+    eng = model.engine()
+    with torch.inference_mode():
+        eng.profile_start()
+        model.forward(batch)
+        prof = eng.profile_stop()
+    return {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+
+
 def positive_batch(cfg, H, W, levels):
     """Like bench.synthetic_batch; variables the model treats as positive get |randn| (aurora.py:733-742 upstream)."""
     b = bench.synthetic_batch(cfg, H, W, 1, "cuda", levels=levels)
@@ -88,7 +98,7 @@ if "highres" in cases:
     batch = bench.synthetic_batch(model.config, 1801, 3600, 1, "cuda")
     ms = timed_rollout(model, batch, 3)
     print(json.dumps({"case": "configs[3] AuroraHighRes 0.1deg 1801x3600 on ONE GPU (LoRA step >= 1)", "ms_per_step": ms,
-                      **mem(model)}), flush=True)
+                      **mem(model), "kernel_ms_per_step": kinds(model, batch)}), flush=True)
     del model, batch
     torch.cuda.empty_cache()
 if "airpollution" in cases:
@@ -97,4 +107,4 @@ if "airpollution" in cases:
     batch = positive_batch(model.config, 451, 900, bench.LEVELS)
     ms = timed_rollout(model, batch, 4)
     print(json.dumps({"case": "configs[4] AuroraAirPollution 0.4deg 451x900, 12 h steps, 1 GPU", "ms_per_step": ms,
-                      **mem(model)}), flush=True)
+                      **mem(model), "kernel_ms_per_step": kinds(model, batch)}), flush=True)
