@@ -1437,6 +1437,7 @@ struct LinearLnArgs {
   const float* bias; const float* gain; const float* shift;
   const float* x_in; int64_t ldx; float* x_out; int64_t ldo; bf16_t* xb; int64_t ldb;
   int64_t M; int k_tiles; float eps;
+  int64_t tile0;   // first tile of this launch
 };
 
 __device__ __forceinline__ float group4_sum(float v) {   // over the 4 lane groups (lanes l, l^16, l^32, l^48)
@@ -1447,17 +1448,25 @@ __device__ __forceinline__ float group4_sum(float v) {   // over the 4 lane grou
   return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
+template <bool FULL>   // FULL: every row of every tile of the launch exists
 __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearLnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;   // waves w and w+4 share a SIMD; wm = 1 runs one phase behind
-  const int64_t m0 = (int64_t)blockIdx.x * FM;
-  // All tiles cost the same, so the CUs of a launch run in lockstep: every main loop at once (HBM idle), then every
-  // epilogue at once (768 KiB per tile against a 256th of the memory system).  Delaying the first-round workgroups of
-  // every other CU by half a tile puts one half's epilogues under the other half's main loops for the whole launch.
-
+  const int64_t m0 = (p.tile0 + blockIdx.x) * FM;
+#ifdef LN_PROBE_TIMES
+  uint64_t ts[8];
+  ts[0] = wall_clock64();
+#define LN_TS(i) ts[i] = wall_clock64()
+#else
+#define LN_TS(i)
+#endif
+  // (Do the CUs of a launch run in lockstep -- every main loop at once with HBM idle, then every epilogue at once?  Holding
+  // the first-round workgroups of every other CU back by 8 ... 55 us changed nothing but the delay itself,
+  // profiles/r04_ab_ln512_stagger.log: a CU's epilogue is as fast as the bytes it keeps in flight allow, whatever its
+  // neighbours do.)
   const char* src_x;
   const char* src_w[4];
   {
@@ -1507,6 +1516,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
   __builtin_amdgcn_s_barrier();   // stage 0 is complete
   asm volatile("" ::: "memory");
   if (wm == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
+  LN_TS(1);
 
   for (int s = 0; s < nt; ++s) {
     u32x4 fw[8], fx[4];
@@ -1536,18 +1546,36 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // the early half waits for the late half's last phase: the ring is dead
   asm volatile("" ::: "memory");
+  LN_TS(2);
 
-  // The residual rows of the first two 16-row passes are requested NOW, before bias / rounding / the two statistics passes:
-  // nothing they need depends on the product, and the ~3 us of statistics hide their HBM round trip.
+  // ---- epilogue.  Where a tile's time goes (profiles/r04_ln512_phases.log, K = 512: 40 us): prologue 3.3, main loop
+  // 15.6, residual requests + bias + rounding 4-6, statistics 2-4, the four passes 12-13.  Every global address below is
+  // a UNIFORM base (scalar arithmetic: tile, wave, pass, row pair) plus one per-lane 32-bit offset computed once, and whole
+  // tiles run without row predicates: 64-bit per-row multiplies and clamps were a quarter of the epilogue's ~3,000
+  // instructions per wave (profiles/r04_ln512_pmc.log).  That bought 1 % (r04_ab_ln512_addressing.log): the epilogue
+  // waits for memory, not for the VALU -- without the residual reads a K = 512 launch takes 318 instead of 385 us, without
+  // the stores 272, without both 234 (r04_ln512_probe_no_residual_no_store.log).  Normalising in the MFMA layout with
+  // packed arithmetic (a lane holds its rows' statistics there) needs ~40 registers more than the 256 there are.
   const int L = lane & 31, half = lane >> 5;
   const int col = wn * 128 + 4 * L;
+  // rows of this tile that exist, counted from this wave's first row (uniform; FULL: all of them, nothing is predicated):
+  // row r of the wave (r = 16 fm + 2 j + half) exists iff r < wave_rows
+  const int wave_rows = FULL ? 64 : (int)(p.M - m0 < FM ? p.M - m0 : FM) - wm * 64;
+  const uint32_t lane_x = (uint32_t)((half * p.ldx + col) * 4);
+  const uint32_t lane_o = (uint32_t)((half * p.ldo + col) * 4);
+  const uint32_t lane_b = (uint32_t)((half * p.ldb + col) * 2);
+  const char* const x_wave = reinterpret_cast<const char*>(p.x_in) + (m0 + wm * 64) * p.ldx * 4;
+  char* const o_wave = reinterpret_cast<char*>(p.x_out) + (m0 + wm * 64) * p.ldo * 4;
+  char* const b_wave = reinterpret_cast<char*>(p.xb) + (m0 + wm * 64) * p.ldb * 2;
+  // The residual rows of the first two 16-row passes are requested NOW, before bias / rounding / the two statistics passes:
+  // nothing they need depends on the product, and the statistics hide their HBM round trip.
   f32x4 xr[3][8];
   auto fetch_x = [&](int fm, f32x4 (&dst)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      int64_t m = m0 + wm * 64 + 16 * fm + 2 * j + half;
-      m = m < p.M ? m : p.M - 1;
-      dst[j] = *reinterpret_cast<const f32x4*>(p.x_in + m * p.ldx + col);
+      const int r = 16 * fm + 2 * j;   // (uniform: scalar address arithmetic)
+      if constexpr (!FULL) dst[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (FULL || r + half < wave_rows) dst[j] = *reinterpret_cast<const f32x4*>(x_wave + (int64_t)(r * (int)p.ldx) * 4 + lane_x);
     }
   };
   fetch_x(0, xr[0]);
@@ -1565,6 +1593,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
                           __uint_as_float(hi & 0xffff0000u)};
     }
   }
+  LN_TS(3);
   // ---- row statistics: two passes over the registers; partial sums of the four n-waves meet in LDS ----
   float* const st_sum = reinterpret_cast<float*>(smem + 65536);   // [128 rows][4 n-waves]
   float* const st_sq = st_sum + 512;
@@ -1606,6 +1635,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
   // ---- 16 rows at a time through this wave's 8 KiB: [16 rows][32 pieces of 16 B], piece P of row r at P ^ c(r) with
   //      c(r) = r ^ 2 (r >> 2): conflict-free for the b128 writes (a lane writes pieces 8g..8g+7 of row i16) and for the
   //      row-major b128 reads (two rows per instruction) under gfx950's 16-lane service groups ----
+  LN_TS(4);
   char* const mine = smem + wave * 8192;
   f32x4 gn = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.gain) gn = *reinterpret_cast<const f32x4*>(p.gain + col);
@@ -1627,19 +1657,33 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
       const int cr = (r16 ^ ((r16 >> 2) << 1)) & 31;
       const f32x4 v = *reinterpret_cast<const f32x4*>(mine + r16 * 512 + ((L ^ cr) << 4));
       const float mu = st_mr[(16 * fm + r16) * 2], rs = st_mr[(16 * fm + r16) * 2 + 1];
-      const int64_t m = m0 + wm * 64 + 16 * fm + r16;
-      if (m < p.M) {
-        const f32x4 x = xr[fm % 3][j];
-        f32x4 o;
-        o.x = fmaf((v.x - mu) * rs, gn.x, sh.x) + x.x;
-        o.y = fmaf((v.y - mu) * rs, gn.y, sh.y) + x.y;
-        o.z = fmaf((v.z - mu) * rs, gn.z, sh.z) + x.z;
-        o.w = fmaf((v.w - mu) * rs, gn.w, sh.w) + x.w;
-        *reinterpret_cast<f32x4*>(p.x_out + m * p.ldo + col) = o;
-        if (p.xb) *reinterpret_cast<u32x2*>(p.xb + m * p.ldb + col) = u32x2{pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
+      const f32x4 x = xr[fm % 3][j];
+      f32x4 o;
+      o.x = fmaf((v.x - mu) * rs, gn.x, sh.x) + x.x;
+      o.y = fmaf((v.y - mu) * rs, gn.y, sh.y) + x.y;
+      o.z = fmaf((v.z - mu) * rs, gn.z, sh.z) + x.z;
+      o.w = fmaf((v.w - mu) * rs, gn.w, sh.w) + x.w;
+      const int rr = 16 * fm + 2 * j;   // (uniform: scalar address arithmetic)
+      if (FULL || rr + half < wave_rows) {
+        *reinterpret_cast<f32x4*>(o_wave + (int64_t)(rr * (int)p.ldo) * 4 + lane_o) = o;
+        if (p.xb)
+          *reinterpret_cast<u32x2*>(b_wave + (int64_t)(rr * (int)p.ldb) * 2 + lane_b) = u32x2{pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
       }
     }
+#ifdef LN_PROBE_TIMES
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ts[5 + (fm & 1)] = wall_clock64();   // (5: passes 0 / 2 done, 6: passes 1 / 3 done -- the last two survive)
+#endif
   }
+#ifdef LN_PROBE_TIMES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ts[7] = wall_clock64();
+  if (p.xb && (tid & 63) == 0) {   // one record per wave in the (unused by the probe) bf16 shadow: row m0 + wave
+    uint64_t* rec = reinterpret_cast<uint64_t*>(p.xb + (m0 + wave) * p.ldb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rec[i] = ts[i];
+  }
+#endif
 }
 
 }  // namespace
@@ -1925,15 +1969,22 @@ extern "C" int aurora_hip_linear_layernorm(const void* A, int64_t lda, const voi
   AURORA_CHECK_ARG((!bias || ((uintptr_t)bias % 16) == 0) && (!gain || ((uintptr_t)gain % 16) == 0) &&
                        (!shift || ((uintptr_t)shift % 16) == 0), "linear_layernorm: unaligned bias / gain / shift");
   LinearLnArgs p{(const char*)A, lda * 2, (const char*)W, ldw * 2, bias, gain, shift, x_in, ldx, x_out, ldo, (bf16_t*)x_bf16, ldb,
-                 M, K / 32, eps};
+                 M, K / 32, eps, 0};
   static bool attr_done_dev[64] = {false};
   bool& attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)linear_ln512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FNST * FSTAGE);
+    (void)hipFuncSetAttribute((const void*)linear_ln512_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FNST * FSTAGE);
+    (void)hipFuncSetAttribute((const void*)linear_ln512_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FNST * FSTAGE);
     attr_done = true;
   }
-  const int64_t blocks = (M + FM - 1) / FM;
-  AURORA_CHECK_ARG(blocks < (int64_t)1 << 31, "linear_layernorm: too many tiles");
-  hipLaunchKernelGGL(linear_ln512_kernel, dim3((unsigned)blocks), dim3(FTHREADS), FNST * FSTAGE, as_stream(stream), p);
+  // whole tiles by the kernel without row predicates; the ragged last tile, if any, by its own one-workgroup launch
+  const int64_t whole = M / FM;
+  AURORA_CHECK_ARG(whole < (int64_t)1 << 31, "linear_layernorm: too many tiles");
+  if (whole > 0)
+    hipLaunchKernelGGL(linear_ln512_kernel<true>, dim3((unsigned)whole), dim3(FTHREADS), FNST * FSTAGE, as_stream(stream), p);
+  if (M % FM != 0) {
+    p.tile0 = whole;
+    hipLaunchKernelGGL(linear_ln512_kernel<false>, dim3(1), dim3(FTHREADS), FNST * FSTAGE, as_stream(stream), p);
+  }
   return check_launch("linear_layernorm");
 }

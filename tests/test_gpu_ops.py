@@ -110,7 +110,7 @@ def test_linear_fp32_two_fp16_terms_full_epilogue(M, N, K, act):
     assert torch.isnan(out[:, N:]).all()
 
 
-@pytest.mark.parametrize("M,K", [(1000, 512), (5000, 2048), (128, 128), (66001, 512)])
+@pytest.mark.parametrize("M,K", [(1000, 512), (5000, 2048), (128, 128), (66001, 512), (65, 512)])   # whole tiles + a ragged one, whole only, ragged only
 @pytest.mark.parametrize("in_place", [True, False])
 def test_linear_layernorm_fused_equals_the_two_kernels(M, K, in_place):
     """bf16 linear + AdaLN + residual in one launch (D = 512) against linear -> layernorm: the same rounded linear result

@@ -4,11 +4,14 @@
 set -e
 NAME=$1; shift
 D=aurora_amd/_lib/var_$NAME; mkdir -p $D
-for f in runtime attention norm embed; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1 -c aurora_amd/csrc/$f.hip -o $D/$f.o &
+CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form=1"
+for f in runtime attention norm embed band model step; do
+  if [ ! -f aurora_amd/_lib/var_cache/$f.o ] || [ aurora_amd/csrc/$f.hip -nt aurora_amd/_lib/var_cache/$f.o ]; then
+    mkdir -p aurora_amd/_lib/var_cache; $CC -c aurora_amd/csrc/$f.hip -o aurora_amd/_lib/var_cache/$f.o &
+  fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c aurora_amd/csrc/gemm.hip -o $D/gemm.o
+$CC "$@" -c aurora_amd/csrc/gemm.hip -o $D/gemm.o
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $D/*.o -o aurora_amd/_lib/libaurora_hip_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC aurora_amd/_lib/var_cache/*.o $D/gemm.o -o aurora_amd/_lib/libaurora_hip_$NAME.so
 rm -rf $D
 echo built aurora_amd/_lib/libaurora_hip_$NAME.so
