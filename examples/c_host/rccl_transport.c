@@ -31,7 +31,7 @@ static double now_s(void) {
 int rccl_transport_init(rccl_transport* t, int rank, int world, const char* id_file, double timeout_s) {
   memset(t, 0, sizeof *t);
   t->rank = rank, t->world = world;
-  if (world < 2 || rank < 0 || rank >= world) T_FAIL(t, "bad rank %d of %d", rank, world);
+  if (world < 1 || rank < 0 || rank >= world) T_FAIL(t, "bad rank %d of %d", rank, world);   /* (world 1: rccl_loopback.c) */
   ncclUniqueId id;
   if (rank == 0) {
     T_NCCL(t, ncclGetUniqueId(&id));
@@ -70,14 +70,21 @@ int rccl_transport_allocate(rccl_transport* t, int64_t staging_bytes) {
   return 0;
 }
 
+/* A band talks to rank - 1 and rank + 1 only; a one-rank communicator may talk to itself (rccl_loopback.c: what a one-GPU
+ * box can exercise of this file). */
+static int peer_ok(const rccl_transport* t, int peer) {
+  if (peer < 0 || peer >= t->world) return 0;
+  return t->world == 1 ? peer == t->rank : abs(peer - t->rank) == 1;
+}
+
 int rccl_transport_post(void* user, const aurora_hip_halo_msg* sends, int32_t n_sends, const aurora_hip_halo_msg* recvs,
                         int32_t n_recvs, void* stream) {
   rccl_transport* t = (rccl_transport*)user;
   for (int i = 0; i < n_sends; ++i)
-    if (sends[i].offset < 0 || sends[i].offset + sends[i].bytes > t->staging_bytes || abs(sends[i].peer - t->rank) != 1)
+    if (sends[i].offset < 0 || sends[i].offset + sends[i].bytes > t->staging_bytes || !peer_ok(t, sends[i].peer))
       T_FAIL(t, "bad send message %d (peer %d, %lld + %lld bytes)", i, sends[i].peer, (long long)sends[i].offset, (long long)sends[i].bytes);
   for (int i = 0; i < n_recvs; ++i)
-    if (recvs[i].offset < 0 || recvs[i].offset + recvs[i].bytes > t->staging_bytes || abs(recvs[i].peer - t->rank) != 1)
+    if (recvs[i].offset < 0 || recvs[i].offset + recvs[i].bytes > t->staging_bytes || !peer_ok(t, recvs[i].peer))
       T_FAIL(t, "bad receive message %d (peer %d, %lld + %lld bytes)", i, recvs[i].peer, (long long)recvs[i].offset, (long long)recvs[i].bytes);
   T_HIP(t, hipEventRecord(t->ready, (hipStream_t)stream));
   T_HIP(t, hipStreamWaitEvent(t->side, t->ready, 0));

@@ -4,6 +4,8 @@ each; their halo exchanges are carried out by copying exactly the staging buffer
 engine."""
 import dataclasses
 import queue
+import subprocess
+from pathlib import Path
 import threading
 
 import pytest
@@ -261,3 +263,84 @@ def test_multiprocess_sharding_on_one_gpu(world, tmp_path):
     err, err_band, shape = ret.get(timeout=10)
     assert shape == (1, 1, 192, 96)
     assert err < 2e-6 and err_band < 2e-6
+
+
+_RCCL_LOOP = r'''
+import os, sys
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29761", RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+try:
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    dist.all_reduce(torch.ones(1, device="cuda"))      # the communicator is created here
+    torch.cuda.synchronize()
+except Exception as e:                                  # no RCCL on this box: not what this test is about
+    print("RCCL-UNAVAILABLE", repr(e)); sys.exit(77)
+from aurora_amd.engine import lib, native
+
+class OneRank:                                          # what _Transport reads of a Shard
+    rank, world, group = 0, 1, None
+
+tr = native._Transport(OneRank(), "cuda")
+n = 1 << 20
+tr.allocate(2 * n)
+pattern = (torch.arange(n, device="cuda") % 251).to(torch.uint8)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    a = torch.randn(4096, 4096, device="cuda")
+    for _ in range(20):                                 # ~10^13 flop queued AHEAD of the fill: the host runs far in front
+        a = (a @ a) * 1e-2
+    tr.send[:n] = pattern + (a[0, 0] * 0).to(torch.uint8)     # ... and the fill depends on that work
+    tr.recv[:n] = 0xEE
+    msgs = (lib.HipHaloMsg * 1)()
+    msgs[0].peer, msgs[0].reserved, msgs[0].offset, msgs[0].bytes = 0, 0, 0, n
+    assert tr._post(None, msgs, 1, msgs, 1, s.cuda_stream) == 0, tr.error   # send to / receive from rank 0 = this rank
+    assert tr._wait(None, s.cuda_stream) == 0, tr.error
+    got = tr.recv[:n].clone()                           # ordered behind the receive by `wait`, on the launch stream
+    tr.send[:n] = 0                                     # overwriting the staging buffer AFTER the send was ordered
+    # the stream assertion: a post on a stream that is not torch's current one must be refused
+    bad = tr._post(None, msgs, 1, msgs, 1, torch.cuda.default_stream().cuda_stream)
+s.synchronize()
+assert bad == -1 and "current stream" in str(tr.error), (bad, tr.error)
+assert torch.equal(got, pattern), int((got != pattern).sum())
+print("RCCL-LOOP-OK", tr.exchanges)
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_carries_a_halo_message_in_stream_order(tmp_path):
+    """The RCCL branch of the halo transport (`_Transport._post`: `batch_isend_irecv` on the NCCL backend, `wait` on the
+    launch stream) on the one GPU there is: a one-rank communicator, the rank its own neighbour -- RCCL's send / receive
+    kernels move the message, ordered behind a producer that is still running when the host posts and in front of the
+    consumer.  What it cannot show is a second GPU; what it does show is that the bytes, the grouping and the stream
+    ordering of the production transport are right.  In its own process, so that a hung collective cannot hang the suite."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_loop.py"
+    script.write_text(_RCCL_LOOP)
+    root = str(Path(__file__).resolve().parents[1])
+    env = dict(os.environ, PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    if r.returncode == 77:
+        pytest.skip("RCCL cannot initialise on this box: " + r.stdout.strip()[-300:])
+    assert r.returncode == 0 and "RCCL-LOOP-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_c_rccl_transport_loops_a_message_back(tmp_path):
+    """The plain-C halo transport (examples/c_host/rccl_transport.c: ncclSend / ncclRecv in one ncclGroup on a side stream,
+    two events against the launch stream) as a one-rank loop-back, examples/c_host/rccl_loopback.c: no Python, no torch in
+    the process.  Together with tests/test_c_host.py (the band mode of the C host links against it) this is what one GPU
+    can verify of the C transport."""
+    root = Path(__file__).resolve().parents[1]
+    src = root / "examples" / "c_host"
+    exe = tmp_path / "rccl_loopback"
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-D_POSIX_C_SOURCE=200809L", "-D__HIP_PLATFORM_AMD__", f"-I{root / 'include'}",
+           f"-I{src}", "-I/opt/rocm/include", str(src / "rccl_loopback.c"), str(src / "rccl_transport.c"), "-L/opt/rocm/lib",
+           "-lamdhip64", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    r = subprocess.run([str(exe), str(tmp_path / "nccl_id")], capture_output=True, text=True, timeout=240)
+    if r.returncode == 77:
+        pytest.skip("RCCL cannot initialise on this box: " + r.stderr.strip()[-300:])
+    assert r.returncode == 0 and "RCCL-LOOPBACK-OK exchanges=1" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
