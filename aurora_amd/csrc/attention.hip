@@ -45,6 +45,11 @@ struct AttnArgs {
   int B; int64_t L; int D; int heads; int n_windows; int N;
   int xcd_order;  // 1: every XCD walks a contiguous range of (window, head) items (the heads of a window run side by side)
   int64_t L_out;  // rows of `out` per batch element; tokens >= L_out (halo rows of a band) are not stored
+  // bf16 kernel: 0 = `qkv` is (B * L, 3 D) token-major; > 0 = head planes (aurora_hip_linear_planes): head h owns a plane of
+  // [B * L rows][q | k | v = 192 elements], planes this many elements apart.  A window's tokens are runs of consecutive
+  // rows, so a plane keeps what an item gathers -- 384 bytes per token -- contiguous in DRAM over each run (token-major
+  // the 128-byte pieces are D * 2 and 3 D * 2 bytes apart): profiles/r04_ab_attention.log (2).
+  int64_t plane_stride;
 };
 
 typedef short bf16x4_t __attribute__((ext_vector_type(4)));
@@ -140,15 +145,21 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
   }
   const bool masked = __syncthreads_or(differs) != 0;
 
-  const bf16_t* const qkv = reinterpret_cast<const bf16_t*>(p.qkv) + (int64_t)b * p.L * 3 * p.D;
-  const int D3 = 3 * p.D;
-  const int col_q = h * HD, col_k = p.D + h * HD, col_v = 2 * p.D + h * HD;
+  const int col_q = h * HD, col_k = p.D + h * HD, col_v = 2 * p.D + h * HD;   // columns of the token-major row (and of the bias)
+  // where this head's q / k / v rows start, and how far apart they are
+  const bf16_t* const base = reinterpret_cast<const bf16_t*>(p.qkv);
+  const bool planes = p.plane_stride != 0;   // (uniform)
+  const int64_t row_stride = planes ? 3 * HD : 3 * p.D;
+  const bf16_t* const rows0 = base + (int64_t)b * p.L * row_stride + (planes ? (int64_t)h * p.plane_stride : 0);
+  const bf16_t* const q_rows = rows0 + (planes ? 0 : col_q);
+  const bf16_t* const k_rows = rows0 + (planes ? HD : col_k);
+  const bf16_t* const v_rows = rows0 + (planes ? 2 * HD : col_v);
 
-  // 16 bytes (8 bf16) of row `t`'s column block starting at `col`.  Loads are issued unconditionally
+  // 16 bytes (8 bf16) of row `t` of q / k / v, `off` elements into the head.  Loads are issued unconditionally
   // (clamped row) so that all of a thread's loads are in flight together; padded rows (t == -1: bias,
   // what Linear(0) yields) and rows beyond the window (t == -2: zeros) are patched afterwards.
-  auto issue = [&](int t, int col) -> u32x4 {
-    return *reinterpret_cast<const u32x4*>(qkv + (int64_t)(t < 0 ? 0 : t) * D3 + col);
+  auto issue = [&](const bf16_t* rows, int t, int off) -> u32x4 {
+    return *reinterpret_cast<const u32x4*>(rows + (int64_t)(t < 0 ? 0 : t) * row_stride + off);
   };
   auto patch = [&](u32x4 v, int t, int col) -> u32x4 {
     if (t >= 0) return v;
@@ -172,8 +183,8 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
     const int idx = tid + it * 192, row = idx >> 3, c = idx & 7;
     trow[it] = (FULL || row < nt * 16) ? s_tok[row] : -3;  // -3: row not staged at all
     if (trow[it] != -3) {
-      kreg[it] = issue(trow[it], col_k + c * 8);
-      vreg[it] = issue(trow[it], col_v + c * 8);
+      kreg[it] = issue(k_rows, trow[it], c * 8);
+      vreg[it] = issue(v_rows, trow[it], c * 8);
     }
   }
   u32x4 qreg[3][2];
@@ -183,8 +194,8 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
     const int qt = wave + 3 * j;
     tq_of[j] = qt < nt ? s_tok[qt * 16 + i16] : -2;
     if (qt < nt) {
-      qreg[j][0] = issue(tq_of[j], col_q + g * 8);
-      qreg[j][1] = issue(tq_of[j], col_q + 32 + g * 8);
+      qreg[j][0] = issue(q_rows, tq_of[j], g * 8);
+      qreg[j][1] = issue(q_rows, tq_of[j], 32 + g * 8);
     }
   }
 #pragma unroll
@@ -413,7 +424,17 @@ extern "C" int aurora_hip_window_attention(const void* qkv, const float* qkv_bia
                                            const int32_t* tok, const uint8_t* grp, int B, int64_t L,
                                            int64_t L_out, int D, int heads, int n_windows, int win_tokens,
                                            int dtype, void* stream) {
+  return aurora_hip_window_attention_planes(qkv, 0, qkv_bias, out, tok, grp, B, L, L_out, D, heads, n_windows, win_tokens, dtype,
+                                            stream);
+}
+
+extern "C" int aurora_hip_window_attention_planes(const void* qkv, int64_t plane_stride, const float* qkv_bias, void* out,
+                                                  const int32_t* tok, const uint8_t* grp, int B, int64_t L,
+                                                  int64_t L_out, int D, int heads, int n_windows, int win_tokens,
+                                                  int dtype, void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "window_attention: bad dtype");
+  AURORA_CHECK_ARG(plane_stride == 0 || (dtype == AURORA_BF16 && plane_stride >= (int64_t)B * L * 3 * HD && plane_stride % 8 == 0),
+                   "window_attention: head planes need bf16 and planes of >= B * L rows (plane_stride=%lld)", (long long)plane_stride);
   AURORA_CHECK_ARG(heads > 0 && D == heads * HD, "window_attention: head_dim must be 64 (D=%d heads=%d)", D, heads);
   AURORA_CHECK_ARG(win_tokens >= 1 && win_tokens <= MAXN, "window_attention: window of %d tokens (max %d)", win_tokens, MAXN);
   AURORA_CHECK_ARG(B > 0 && n_windows > 0 && L > 0 && L_out > 0 && L_out <= L, "window_attention: empty problem");
@@ -426,7 +447,7 @@ extern "C" int aurora_hip_window_attention(const void* qkv, const float* qkv_bia
   // CUs of one XCD instead of by eight XCDs at unrelated times: 4.55 -> 4.94 TB/s at stage 0, 4.18 -> 4.58 at stage 1
   // (isolated); a launch of a few thousand items (stage 2, a latitude band) is latency-bound and keeps the plain order.
   const int xcd_order = blocks >= 6000 ? 1 : 0;
-  AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens, xcd_order, L_out};
+  AttnArgs p{qkv, qkv_bias, out, tok, grp, B, L, D, heads, n_windows, win_tokens, xcd_order, L_out, plane_stride};
   if (dtype == AURORA_BF16) {
     // one workgroup per (window, head); full 144-token windows store whole 128-byte rows
     if (win_tokens != MAXN)

@@ -66,7 +66,20 @@ struct LinearArgs {
   // split-K (linear_kernel_256pp, MODE 1): workgroup b multiplies K-slice b / n_blocks of tile b % n_blocks; slices
   // meet through fp32 slabs (256 KiB per slice and tile) and a ticket per tile -- the last arriver adds up and finishes
   int split; float* slabs; int32_t* tickets;
+  // head planes (aurora_hip_linear_planes; 0: rows of ldc elements): the 64-column blocks of the result are q | k | v of
+  // the attention heads (block sel * plane_heads + h); head h owns a plane of [M rows][q | k | v = 192 elements],
+  // plane_stride elements after the previous head's
+  int64_t plane_stride; int plane_heads;
 };
+
+// Element (m, n) of the result (n a multiple of 16: a 16-element piece never straddles two 64-column blocks).
+template <typename T>
+__device__ __forceinline__ T* out_piece(const LinearArgs& p, int64_t m, int n) {
+  T* const c = reinterpret_cast<T*>(p.C);
+  if (!p.plane_stride) return c + m * p.ldc + n;
+  const int blk = n >> 6, sel = blk / p.plane_heads, h = blk - sel * p.plane_heads;
+  return c + (int64_t)h * p.plane_stride + m * 192 + sel * 64 + (n & 63);
+}
 
 // The problem of a strided batch this workgroup belongs to (blockIdx.y; a plain launch has one problem and zero strides).
 __device__ __forceinline__ LinearArgs batch_problem(const LinearArgs& in) {
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(THREADS, 2) void linear_kernel(const LinearArgs p_i
           if (t < n_left) v[t] += rp[t];
       }
     }
-    store16<T>(reinterpret_cast<T*>(p.C) + m * p.ldc + nbase, v, vec, n_left);
+    store16<T>(out_piece<T>(p, m, nbase), v, vec, n_left);
     if (p.C2) store16<T2>(reinterpret_cast<T2*>(p.C2) + m * p.ldc2 + nbase, v, vec, n_left);
   }
 }
@@ -395,7 +408,7 @@ __device__ __forceinline__ void epilogue_256(const LinearArgs& p, f32x4 (&acc)[4
           if (t < n_left) v[t] += rp[t];
       }
     }
-    store16<T>(reinterpret_cast<T*>(p.C) + m * p.ldc + nbase, v, vec, n_left);
+    store16<T>(out_piece<T>(p, m, nbase), v, vec, n_left);
     if (p.C2) store16<T2>(reinterpret_cast<T2*>(p.C2) + m * p.ldc2 + nbase, v, vec, n_left);
   }
 }
@@ -417,7 +430,9 @@ __device__ __forceinline__ void epilogue_256_bf16_coalesced(const LinearArgs& p,
 #pragma unroll
   for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
   const int rr = lane >> 3, cc = lane & 7;
-  bf16_t* cbase = reinterpret_cast<bf16_t*>(p.C) + n0 + wn * 64 + cc * 8;
+  // (head planes: the wave's 64 columns are q, k or v of ONE head: 128-byte pieces of its plane's 384-byte rows)
+  bf16_t* cbase = out_piece<bf16_t>(p, 0, n0 + wn * 64) + cc * 8;
+  const int64_t ld_rows = p.plane_stride ? 192 : p.ldc;
 #pragma unroll
   for (int part = 0; part < PARTS; ++part) {
 #pragma unroll
@@ -454,7 +469,7 @@ __device__ __forceinline__ void epilogue_256_bf16_coalesced(const LinearArgs& p,
       const int row = it * 8 + rr;
       const u32x4 d = *reinterpret_cast<const u32x4*>(mine + row * 128 + ((cc ^ rr) << 4));
       const int64_t m = m0 + wm * 128 + part * (128 / PARTS) + row;
-      if (m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * p.ldc));
+      if (m < p.M) __builtin_nontemporal_store(d, reinterpret_cast<u32x4*>(cbase + m * ld_rows));
     }
   }
 }
@@ -1742,7 +1757,7 @@ namespace {
 int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, void* C2,
                 int64_t ldc2, const float* residual, int64_t ldr, int64_t M, int N, int K, int dtype, int act, int f32_gemm,
                 const float* guard, float guard_limit, int batch, int64_t stride_a, int64_t stride_w, int64_t stride_bias,
-                int64_t stride_c, void* stream, const SplitWs* ws = nullptr);
+                int64_t stride_c, void* stream, const SplitWs* ws = nullptr, int64_t plane_stride = 0, int plane_heads = 0);
 }
 
 extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, int64_t ldw,
@@ -1752,6 +1767,13 @@ extern "C" int aurora_hip_linear_ex(const void* A, int64_t lda, const void* W, i
                                     void* stream) {
   return linear_impl(A, lda, W, ldw, bias, C, ldc, C2, ldc2, residual, ldr, M, N, K, dtype, act, f32_gemm, guard, guard_limit,
                      1, 0, 0, 0, 0, stream);
+}
+
+extern "C" int aurora_hip_linear_planes(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
+                                        int64_t plane_stride, int heads, int64_t M, int N, int K, int dtype, void* stream) {
+  AURORA_CHECK_ARG(plane_stride > 0 && heads > 0, "linear_planes: plane_stride=%lld heads=%d", (long long)plane_stride, heads);
+  return linear_impl(A, lda, W, ldw, bias, C, N, nullptr, 0, nullptr, 0, M, N, K, dtype, AURORA_ACT_NONE, -1, nullptr, 0.f, 1, 0,
+                     0, 0, 0, stream, nullptr, plane_stride, heads);
 }
 
 extern "C" int aurora_hip_linear_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
@@ -1781,8 +1803,12 @@ namespace {
 int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc, void* C2,
                 int64_t ldc2, const float* residual, int64_t ldr, int64_t M, int N, int K, int dtype, int act, int f32_gemm,
                 const float* guard, float guard_limit, int batch, int64_t stride_a, int64_t stride_w, int64_t stride_bias,
-                int64_t stride_c, void* stream, const SplitWs* ws) {
+                int64_t stride_c, void* stream, const SplitWs* ws, int64_t plane_stride, int plane_heads) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "linear: bad dtype %d", dtype);
+  AURORA_CHECK_ARG(plane_stride == 0 || (dtype == AURORA_BF16 && plane_heads > 0 && N % (64 * plane_heads) == 0 &&
+                                         N <= 192 * plane_heads && plane_stride >= M * 192 && plane_stride % 8 == 0 &&
+                                         C2 == nullptr && residual == nullptr && batch == 1),
+                   "linear: head planes need bf16, N = 64 heads x (1, 2 or 3), planes of >= M rows, one output, no residual");
   const int pre = f32_gemm < 0 ? 0 : f32_gemm & (AURORA_F32_A_SPLIT | AURORA_F32_W_SPLIT | AURORA_F32_C_SPLIT);
   if (pre) f32_gemm &= ~pre;
   AURORA_CHECK_ARG(f32_gemm >= -1 && f32_gemm <= 2, "linear: bad fp32 GEMM mode %d", f32_gemm);
@@ -1874,6 +1900,8 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
 
   p.bs_a = stride_a * es; p.bs_w = stride_w * es; p.bs_c = stride_c * es; p.bs_bias = stride_bias;
   p.split = ksplit; p.slabs = ksplit > 1 ? ws->slabs : nullptr; p.tickets = ksplit > 1 ? ws->tickets : nullptr;
+  p.plane_stride = plane_stride; p.plane_heads = plane_heads;
+  if (plane_stride) p.vec_store = ((uintptr_t)C % 16) == 0 ? 1 : 0;   // (rows of a plane are 128 bytes: ldc plays no part)
   dim3 grid((unsigned)p.n_blocks, (unsigned)batch);
   static bool attr_done_dev[64] = {false};   // function attributes are per device
   bool& attr_done = attr_done_dev[current_device() & 63];

@@ -209,9 +209,11 @@ struct aurora_hip_model {
   void* stage_recv = nullptr;
   int64_t staging_bytes = 0, staging_need = 0;
   bool sharded() const { return band.world > 1; }
-  // process defaults read ONCE, when the handle is created (never inside a step): AURORA_FUSE_LN, AURORA_BAND_SPLIT_ATTENTION
+  // process defaults read ONCE, when the handle is created (never inside a step): AURORA_FUSE_LN,
+  // AURORA_BAND_SPLIT_ATTENTION, AURORA_QKV_PLANES
   int fuse_ln = 1;
   bool split_attention = false;
+  bool qkv_planes = true;   // bf16 blocks: q | k | v leave the qkv linear one attention head per plane (aurora_hip_linear_planes)
 
   // per step
   aurora::DevBuf abs_enc, dyn_planes, ctx_max;
@@ -311,6 +313,13 @@ struct Launcher {
                                   limit, stream);
     });
     m.arena.top = mark;   // (stream order: the next launch that takes this memory runs after this one)
+  }
+  // the qkv linear of a block with its result in head planes (bf16)
+  void linear_planes(const void* A, int64_t lda, const void* Wt, int64_t ldw, const float* bias, void* C, int64_t plane_stride,
+                     int heads, int64_t M, int N, int K) {
+    timed(m, stream, K_LINEAR_BF16, 2.0 * (double)M * N * K, [&] {
+      return aurora_hip_linear_planes(A, lda, Wt, ldw, bias, C, plane_stride, heads, M, N, K, AURORA_BF16, stream);
+    });
   }
   void layernorm(const void* y, int64_t ldy, const float* gain, const float* shift, const float* res, int64_t ldr,
                  int64_t res_mod, float* out_f32, int64_t ldo, void* out_t, int64_t ldt, int64_t M, int D, float eps,

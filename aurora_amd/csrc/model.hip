@@ -650,6 +650,7 @@ extern "C" int aurora_hip_create(const aurora_hip_config* c, aurora_hip_model** 
     m->ctx_max = DevBuf(16);
     if (const char* e = getenv("AURORA_FUSE_LN")) m->fuse_ln = atoi(e);
     if (const char* e = getenv("AURORA_BAND_SPLIT_ATTENTION")) m->split_attention = atoi(e) != 0;
+    if (const char* e = getenv("AURORA_QKV_PLANES")) m->qkv_planes = atoi(e) != 0;
     m->tickets = DevBuf(SPLIT_TICKETS * sizeof(int32_t));
     hip_ok(hipMemset(m->tickets.p, 0, SPLIT_TICKETS * sizeof(int32_t)), "hipMemset");
     *out = m.release();

@@ -354,15 +354,27 @@ void run_step(Model& m, const StepIO& s, void* stream) {
       const void* a_in = bf ? xb : (const void*)xf;
       const size_t mark = A.top;
       void* ao = nullptr;
+      // bf16 blocks: q | k | v in head planes (head h: [rows][q | k | v = 192]) -- what the attention gathers per (token,
+      // head) is then 384 contiguous bytes, and a window's runs of consecutive tokens are contiguous in DRAM
+      // (m.qkv_planes, AURORA_QKV_PLANES=0 at creation: rows of 3 dim).  Same bytes, same arithmetic; the planes of a
+      // band have own + halo rows.
+      const bool planes = bf && m.qkv_planes;
+      int64_t plane_stride = 0;   // elements; set where qkv is allocated
       auto attend = [&](const void* qkv, const int32_t* tok, const uint8_t* grp, int n_windows, int n_tok, int64_t Lq, int64_t Lo) {
         // algorithmic bytes: q, k, v read + o written once over the (padded) windows
         timed(m, stream, K_WINDOW_ATTENTION, 4.0 * B * n_windows * n_tok * dim * es, [&] {
-          return aurora_hip_window_attention(qkv, blk.qkv_b, ao, tok, grp, B, Lq, Lo, dim, blk.heads, n_windows, n_tok, bb, stream);
+          return aurora_hip_window_attention_planes(qkv, plane_stride, blk.qkv_b, ao, tok, grp, B, Lq, Lo, dim, blk.heads, n_windows,
+                                                    n_tok, bb, stream);
         });
       };
       if (!sharded) {
         void* qkv = A.take((size_t)M * 3 * dim * es);
-        L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
+        if (planes) {
+          plane_stride = M * 192;
+          L.linear_planes(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, plane_stride, blk.heads, M, 3 * dim, dim);
+        } else {
+          L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
+        }
         const DevTables& tb = tables_for(m, stage, blk.shifted);
         ao = A.take((size_t)M * dim * es);
         attend(qkv, (const int32_t*)tb.tok.p, tb.has_grp ? (const uint8_t*)tb.grp.p : nullptr, tb.n_windows, tb.n_tok, Ls, Ls);
@@ -372,6 +384,8 @@ void run_step(Model& m, const StepIO& s, void* stream) {
         REQUIRE(pl.n_own == Ls, "band plan of stage %d holds %d rows, the step %lld", stage, pl.n_own, (long long)Ls);
         const int64_t Lq = Ls + pl.n_halo;
         char* qkv = (char*)A.take((size_t)Lq * 3 * dim * es);
+        REQUIRE(!planes || B == 1, "a latitude band runs one batch element");
+        if (planes) plane_stride = Lq * 192;
         ao = A.take((size_t)M * dim * es);
         const int32_t* tok = (const int32_t*)pl.tok.p;
         const uint8_t* grp = pl.has_grp ? (const uint8_t*)pl.grp.p : nullptr;
@@ -405,7 +419,8 @@ void run_step(Model& m, const StepIO& s, void* stream) {
             REQUIRE(rc == 0, "the host's halo `post` callback failed (%d)", rc);
           }
         }
-        L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
+        if (planes) L.linear_planes(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, plane_stride, blk.heads, M, 3 * dim, dim);
+        else L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
         if (exchange) {
           // The halo rows were posted ahead of the qkv GEMM above, so the transfer has that whole GEMM to hide under.  By
           // default ALL windows then run in one launch behind the halo projection: a band's interior / boundary launches
@@ -421,7 +436,10 @@ void run_step(Model& m, const StepIO& s, void* stream) {
           const char* w_kv = (const char*)aw.qkv[bi] + (size_t)dim * dim * es;
           const int n_recv = pl.recv_cnt[0] + pl.recv_cnt[1];
           const int first = pl.recv_cnt[0] > 0 ? pl.recv_off[0] : pl.recv_off[1];   // the two neighbours' halo rows are adjacent
-          if (n_recv > 0)
+          if (n_recv > 0 && planes)   // k | v of rows Ls + first ... of every head's plane (64 elements into the row: behind q)
+            L.linear_planes(m.stage_recv, dim, w_kv, dim, blk.qkv_b + dim, qkv + ((size_t)(Ls + first) * 192 + 64) * es, plane_stride,
+                            blk.heads, n_recv, 2 * dim, dim);
+          else if (n_recv > 0)
             L.linear(m.stage_recv, dim, w_kv, dim, blk.qkv_b + dim, qkv + ((size_t)(Ls + first) * 3 * dim + dim) * es, 3 * dim, n_recv,
                      2 * dim, dim, bb);
           const int w0 = (m.split_attention && pl.n_interior > 0) ? pl.n_interior : 0;

@@ -75,6 +75,10 @@ _SIGNATURES = {
                                   c_int, c_void_p]),
     "aurora_hip_window_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                             c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "aurora_hip_window_attention_planes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                   c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "aurora_hip_linear_planes": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int64,
+                                         c_int, c_int, c_int, c_void_p]),
     "aurora_hip_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                        c_void_p]),
     "aurora_hip_layernorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
@@ -382,11 +386,37 @@ def linear_layernorm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     return x_out
 
 
+def linear_planes(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, sel0: int = 0) -> torch.Tensor:
+    """out[h, m, sel0 + sel, :] = (a @ w.T + bias)[m, (sel * heads + h) * 64 : +64]: `out` is (heads, rows >= M, 3, 64) bf16 --
+    q | k | v of a token next to each other, one attention head per plane.  `sel0` = 1: w holds the k | v rows only."""
+    M, K = a.shape
+    N = w.shape[0]
+    heads = out.shape[0]
+    assert a.dtype == w.dtype == out.dtype == torch.bfloat16 and a.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
+    assert out.dim() == 4 and out.shape[2:] == (3, 64) and out.shape[1] >= M and N == (3 - sel0) * 64 * heads
+    assert out.stride(3) == 1 and out.stride(2) == 64 and out.stride(1) == 192   # (a row range of longer planes is fine)
+    c = out[0, 0, sel0]
+    with _Timed("linear_bf16", 2.0 * M * N * K):
+        _check(load().aurora_hip_linear_planes(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(c), out.stride(0), heads,
+                                               M, N, K, dtype_code(a.dtype), _stream()))
+    return out
+
+
 def window_attention(qkv: torch.Tensor, qkv_bias: Optional[torch.Tensor], out: torch.Tensor,
                      tok: torch.Tensor, grp: Optional[torch.Tensor], B: int, L: int, D: int,
-                     heads: int, L_out: Optional[int] = None) -> torch.Tensor:
-    """`L` rows of qkv per batch element ([owned | halo] for a latitude band), `L_out` rows of out."""
+                     heads: int, L_out: Optional[int] = None, planes: bool = False) -> torch.Tensor:
+    """`L` rows of qkv per batch element ([owned | halo] for a latitude band), `L_out` rows of out.  `planes`: qkv is
+    (heads, B * L, 3, 64), what `linear_planes` writes."""
     L_out = L if L_out is None else L_out
+    if planes:
+        assert qkv.is_contiguous() and qkv.shape == (heads, B * L, 3, 64) and qkv.dtype == torch.bfloat16
+        assert out.numel() == B * L_out * D and out.dtype == qkv.dtype and tok.dtype == torch.int32 and tok.dim() == 2
+        n_windows, n_tok = tok.shape
+        with _Timed("window_attention_bf16", 4.0 * B * n_windows * n_tok * D * 2):
+            _check(load().aurora_hip_window_attention_planes(_ptr(qkv), qkv.stride(0), _ptr(qkv_bias), _ptr(out), _ptr(tok), _ptr(grp),
+                                                             B, L, L_out, D, heads, n_windows, n_tok, dtype_code(qkv.dtype),
+                                                             _stream()))
+        return out
     assert qkv.is_contiguous() and out.is_contiguous() and qkv.numel() == B * L * 3 * D
     assert out.numel() == B * L_out * D and out.dtype == qkv.dtype
     assert tok.dtype == torch.int32 and tok.is_contiguous() and tok.dim() == 2

@@ -104,6 +104,17 @@ int aurora_hip_linear_ws(const void* A, int64_t lda, const void* W, int64_t ldw,
                          int act, void* workspace, int64_t workspace_bytes, int32_t* tickets, int n_tickets, int split,
                          void* stream);
 
+/* The qkv linear of a Swin block (swin3d.py:153) with its result in HEAD PLANES instead of rows: the 64-column blocks of
+ * C = A W^T + bias are q, k, v of the attention heads (block sel * heads + h, swin3d.py:154-156 reshapes exactly these);
+ * head h owns a plane of [M rows][q | k | v = 192 elements] bf16, `plane_stride` elements (>= 192 M, a multiple of 8)
+ * behind the previous head's.  The window attention gathers q, k and v of one (token, head) at a time: in a plane that is
+ * 384 contiguous bytes, and a window's runs of consecutive tokens are contiguous runs of DRAM; in rows of 3 D elements
+ * they are three 128-byte pieces D * 2 bytes apart, every token 3 D * 2 bytes further (aurora_hip_window_attention_planes
+ * reads this layout).  N = 64 heads x 3, or x 2 / x 1 with C moved 64 / 128 elements into the row (k | v of halo rows).
+ * bf16 only; same arithmetic and bits as aurora_hip_linear. */
+int aurora_hip_linear_planes(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
+                             int64_t plane_stride, int heads, int64_t M, int N, int K, int dtype, void* stream);
+
 /* Mode 2 with operands that are ALREADY split (flags OR-ed into f32_gemm = 2): the split is the same arithmetic wherever
  * it happens, so results are bit-identical to plain mode 2, but a GEMM whose operands arrive split spends no VALU work
  * on them -- the two-term kernel goes from 0.29 to 0.40 PFLOP/s fp32-equivalent when both do.
@@ -152,6 +163,13 @@ int aurora_hip_window_attention(const void* qkv, const float* qkv_bias, void* ou
                                 const int32_t* tok, const uint8_t* grp,
                                 int B, int64_t L, int64_t L_out, int D, int heads, int n_windows,
                                 int win_tokens, int dtype, void* stream);
+/* The same with q | k | v in head planes (aurora_hip_linear_planes): head h owns [B * L rows][q | k | v = 192 elements]
+ * bf16, planes `plane_stride` elements apart (>= 192 B L); row b * L + t is token t of batch element b.
+ * plane_stride = 0: the row layout above.  Same results, bit for bit. */
+int aurora_hip_window_attention_planes(const void* qkv, int64_t plane_stride, const float* qkv_bias, void* out,
+                                       const int32_t* tok, const uint8_t* grp,
+                                       int B, int64_t L, int64_t L_out, int D, int heads, int n_windows,
+                                       int win_tokens, int dtype, void* stream);
 
 /* ---- (adaptive) layer norm with residual --------------------------------------------------
  * out[r,:] = res[r % res_mod? ,:] + LN(y[r,:]) * gain[:] + shift[:]   (res nullable)

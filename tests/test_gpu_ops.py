@@ -455,6 +455,52 @@ def test_window_attention(res, window, heads, shifted, dtype):
     assert relerr(out.float(), ref) < tol
 
 
+@pytest.mark.parametrize("M,heads,K", [(300, 2, 128), (1300, 8, 512), (70000, 8, 512), (2160, 32, 2048), (257, 4, 64)])
+def test_linear_planes_and_attention_on_planes_equal_the_row_layout(M, heads, K):
+    """q | k | v of a token side by side, one attention head per plane (aurora_hip_linear_planes ->
+    aurora_hip_window_attention_planes): every kernel
+    the dispatcher may pick for these shapes (128 x 128, 256 x 128, 256 x 256 tiles) writes the same bits to the same
+    (row, column) as the row layout, planes longer than M leave their tail alone, and the attention reads them to the same
+    output bit for bit."""
+    from aurora_amd.engine import geometry
+
+    L = lib()
+    D = 64 * heads
+    a = rnd(M, K, seed=1).bfloat16().to(DEV)
+    w = rnd(3 * D, K, seed=2, scale=K ** -0.5).bfloat16().to(DEV)
+    b = rnd(3 * D, seed=3).float().to(DEV)
+    rows = torch.empty((M, 3 * D), dtype=torch.bfloat16, device=DEV)
+    L.linear(a, w, b, rows)
+    pad = 5
+    planes = torch.full((heads, M + pad, 3, 64), 9.0, dtype=torch.bfloat16, device=DEV)
+    L.linear_planes(a, w, b, planes)
+    torch.cuda.synchronize()
+    as_rows = lambda pl: pl.permute(1, 2, 0, 3).reshape(pl.shape[1], -1)   # (rows, sel, head, 64) -> (rows, sel * D)  # noqa: E731
+    assert torch.equal(as_rows(planes[:, :M]), rows)
+    assert (planes[:, M:] == 9.0).all()
+    # a latitude band's halo projection: k | v only, written into rows [M - 7, M) behind the q part of every row
+    kv = torch.full_like(planes, 3.0)
+    L.linear_planes(a[:7], w[D:], b[D:], kv[:, M - 7:], sel0=1)   # (a row range: the plane stride is the whole buffer's)
+    torch.cuda.synchronize()
+    assert torch.equal(as_rows(kv[:, M - 7:M, 1:]), rows[:7, D:])
+    assert (kv[:, :, 0] == 3.0).all() and (kv[:, :M - 7] == 3.0).all() and (kv[:, M:] == 3.0).all()
+    # attention over windows of the first tokens (one batch element; the planes keep their padding rows)
+    res = (2, 6, 12) if M >= 144 else None
+    if res is None:
+        return
+    n_tok_grid = min(M // 144, 40) * 144
+    grid = (2, 6, 12 * (n_tok_grid // 144))
+    tok, grp, _ = geometry.window_tables(grid, (2, 6, 12), True)
+    tok_d, grp_d = torch.from_numpy(tok).to(DEV), None if grp is None else torch.from_numpy(grp).to(DEV)
+    Lt = n_tok_grid
+    out_rows = torch.zeros((Lt, D), dtype=torch.bfloat16, device=DEV)
+    out_planes = torch.ones_like(out_rows)
+    L.window_attention(rows[:Lt].contiguous(), b, out_rows, tok_d, grp_d, 1, Lt, D, heads)
+    L.window_attention(planes[:, :Lt].contiguous(), b, out_planes, tok_d, grp_d, 1, Lt, D, heads, planes=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out_rows, out_planes)
+
+
 # ------------------------------------------------------------------------------------------
 # layer norms
 # ------------------------------------------------------------------------------------------
