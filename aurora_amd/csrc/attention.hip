@@ -128,8 +128,11 @@ __global__ __launch_bounds__(192) void window_attention_bf16(const AttnArgs p) {
     const uint32_t nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = item & 7, idx = item >> 3;
     item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
   }
-  const int h = item % p.heads;
-  const int w = (item / p.heads) % p.n_windows;
+  // rows of 3 D: the heads of a window side by side (pieces of the same token rows); head planes: the windows of a head
+  // side by side (neighbouring windows continue each other's runs of rows in the same plane)
+  const bool head_major = p.plane_stride != 0;   // (6.24 -> 6.14 ms per step against window-major on planes)
+  const int h = head_major ? (item / p.n_windows) % p.heads : item % p.heads;
+  const int w = head_major ? item % p.n_windows : (item / p.heads) % p.n_windows;
   const int b = item / (p.heads * p.n_windows);
 
   // Token / group tables of this window; the -100 mask only matters if the window really mixes groups.
