@@ -198,7 +198,10 @@ __device__ __forceinline__ float group_sum(float v) {
 // Chosen from Lq at launch: 3 for the encoder's three latent queries (a chunk of 4 computed a fourth, discarded, query: a
 // third more arithmetic), 7 for the decoder's thirteen level queries (7 + 6: two passes over the three keys instead of four,
 // and 14 slots for 13 queries instead of 16), 4 otherwise.
-template <typename T, int HDIM, int QC>
+// FEWK: at most four keys (the decoder's three latent levels): the column's keys and values are read ONCE, into
+// registers, for all query chunks, and a query's softmax is taken over its (<= 4) scores at once -- one exponential per
+// score and no running-maximum rescaling of the output (the online form: two exponentials and a rescale per key).
+template <typename T, int HDIM, int QC, bool FEWK = false>
 __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs p) {
   constexpr int LPG = HDIM / 4;   // lanes per (column, head)
   const int inner = p.heads * HDIM;
@@ -214,6 +217,15 @@ __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs
   const bool pairs = std::is_same<T, float>::value && p.pair_guard != nullptr && *p.pair_guard < p.pair_limit;   // (uniform)
   const T* kv0 = reinterpret_cast<const T*>(p.kv) + (b * p.kv_bstride + l) * (2 * (int64_t)inner) + h * HDIM + d0;
   const int64_t kv_step = p.kv_lstride * (2 * (int64_t)inner);
+  float kk[FEWK ? 4 : 1][4], vv[FEWK ? 4 : 1][4];
+  if constexpr (FEWK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const T* kp = kv0 + (j < p.Lk ? j : 0) * kv_step;   // (a slot past Lk repeats key 0; its weight is zero)
+      load4(kp, kk[j]);
+      load4(kp + inner, vv[j]);
+    }
+  }
   for (int i0 = 0; i0 < p.Lq; i0 += QC) {
     float qv[QC][4], o[QC][4], mx[QC], sum[QC];
 #pragma unroll
@@ -224,8 +236,26 @@ __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs
       mx[c] = -INFINITY;
       sum[c] = 0.f;
     }
+    if constexpr (FEWK) {
+#pragma unroll
+      for (int c = 0; c < QC; ++c) {
+        float sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = fmaf(qv[c][0], kk[j][0], fmaf(qv[c][1], kk[j][1], fmaf(qv[c][2], kk[j][2], qv[c][3] * kk[j][3])));
+          sc[j] = j < p.Lk ? group_sum<LPG>(d) * scale : -INFINITY;
+        }
+        const float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = __expf(sc[j] - m);   // (exp(-inf) = 0 for the slots past Lk)
+        sum[c] = (e[0] + e[1]) + (e[2] + e[3]);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[c][d] = fmaf(e[0], vv[0][d], fmaf(e[1], vv[1][d], fmaf(e[2], vv[2][d], e[3] * vv[3][d])));
+      }
+    }
 #pragma unroll 4   // (several keys' loads in flight; the online-softmax chain only orders the arithmetic)
-    for (int j = 0; j < p.Lk; ++j) {
+    for (int j = 0; j < (FEWK ? 0 : p.Lk); ++j) {
       const T* kp = kv0 + j * kv_step;
       float k4[4], v4[4];
       load4(kp, k4);
@@ -480,6 +510,7 @@ extern "C" int aurora_hip_perceiver_attention_ex(const void* q, int64_t q_col_st
 #define AURORA_PERC(TT, HDIM)                                                                                              \
   do {                                                                                                                   \
     if (Lq % 3 == 0 && Lq <= 6) hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM, 3>), grid, block, 0, as_stream(stream), p); \
+    else if (Lq > 8 && HDIM <= 64 && Lk <= 4) hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM, 7, true>), grid, block, 0, as_stream(stream), p); \
     else if (Lq > 8 && HDIM <= 64) hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM, 7>), grid, block, 0, as_stream(stream), p); \
     else hipLaunchKernelGGL((perceiver_attention_kernel<TT, HDIM, 4>), grid, block, 0, as_stream(stream), p);              \
   } while (0)

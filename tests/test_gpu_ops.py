@@ -628,7 +628,7 @@ def test_unpatchify_matches_oracle(P, Wp):
     assert relerr(out.permute(1, 0, 2, 3, 4), ref) < 2e-6
 
 
-@pytest.mark.parametrize("Lq,Lk,hd", [(3, 13, 32), (13, 3, 64), (3, 4, 16)])
+@pytest.mark.parametrize("Lq,Lk,hd", [(3, 13, 32), (13, 3, 64), (3, 4, 16), (13, 1, 64), (9, 4, 64), (13, 5, 64)])   # <= 4 keys: the few-keys form
 def test_perceiver_attention(Lq, Lk, hd):
     L = lib()
     B, cols, heads = 2, 50, 4
