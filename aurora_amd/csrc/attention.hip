@@ -71,11 +71,14 @@ __device__ __forceinline__ float vmax2(float a, float b) {
   return r;
 }
 // The -100 mask (swin3d.py:357-358) of four keys at once: x holds (key group) ^ (query group) per byte, 0 for the same
-// group.  A key of another group gets -100 * (x byte) instead of -100: x >= 1, and e^-100 relative to the row maximum (a
-// key of the query's own group is always present) is already below fp32's resolution of the sum and rounds to zero in the
-// bf16 probabilities -- nothing observable changes, and the mask costs a byte conversion and an FMA per score
-// (v_cvt_f32_ubyteN, v_fmac) instead of compare + select + add.
+// group.  Every non-zero byte becomes 1 (the carry-free "has a non-zero byte" trick: bit 7 of ((b & 0x7f) + 0x7f) | b is set
+// iff b != 0), so a key of another group gets the reference's literal -100 -- not -100 * (group difference), which round 4
+// shipped: identical after rounding for any realistic score range, but an out-of-group key whose raw score exceeds the
+// in-group maximum by more than ~90 would have differed (tests/test_gpu_ops.py pins it with such a key).  The mask then
+// costs five integer operations per FOUR keys plus a byte conversion and an FMA per score (v_cvt_f32_ubyteN, v_fmac);
+// the kernel is HBM-bound, not issue-bound (profiles/r04_ab_attention.log).
 __device__ __forceinline__ void mask4(f32x4& s, uint32_t x) {
+  x = ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7) & 0x01010101u;
   s.x = fmaf((float)(x & 0xffu), -100.0f * 8.0f, s.x);   // pre-scale: multiplied by 1/8 later
   s.y = fmaf((float)((x >> 8) & 0xffu), -100.0f * 8.0f, s.y);
   s.z = fmaf((float)((x >> 16) & 0xffu), -100.0f * 8.0f, s.z);

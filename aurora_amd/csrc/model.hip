@@ -142,6 +142,24 @@ hipEvent_t take_event(Model& m) {
   return e;
 }
 
+hipStream_t side_stream(Model& m, int i) {
+  while ((int)m.side_streams.size() < i) {
+    hipStream_t st;
+    hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    m.side_streams.push_back(st);
+  }
+  return m.side_streams[i - 1];
+}
+
+hipEvent_t sync_event(Model& m) {
+  if (m.sync_next == m.sync_events.size()) {
+    hipEvent_t e;
+    hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    m.sync_events.push_back(e);
+  }
+  return m.sync_events[m.sync_next++];
+}
+
 int bounded_mode() {
   static const int mode = getenv("AURORA_F32_GEMM") ? -1 : 2;
   return mode;
@@ -651,6 +669,10 @@ extern "C" int aurora_hip_create(const aurora_hip_config* c, aurora_hip_model** 
     if (const char* e = getenv("AURORA_FUSE_LN")) m->fuse_ln = atoi(e);
     if (const char* e = getenv("AURORA_BAND_SPLIT_ATTENTION")) m->split_attention = atoi(e) != 0;
     if (const char* e = getenv("AURORA_QKV_PLANES")) m->qkv_planes = atoi(e) != 0;
+    if (const char* e = getenv("AURORA_SPLIT_K")) m->split_k = atoi(e) != 0;
+    if (const char* e = getenv("AURORA_ROW_CHUNKS")) m->row_chunks = std::min(4, std::max(1, atoi(e)));
+    if (const char* e = getenv("AURORA_CHUNK_SYNC")) m->chunk_sync = atoi(e);
+    if (const char* e = getenv("AURORA_CHUNK_MIN_ROWS")) m->chunk_min_rows = std::max(256, atoi(e));
     m->tickets = DevBuf(SPLIT_TICKETS * sizeof(int32_t));
     hip_ok(hipMemset(m->tickets.p, 0, SPLIT_TICKETS * sizeof(int32_t)), "hipMemset");
     *out = m.release();
@@ -1222,7 +1244,12 @@ extern "C" int aurora_hip_step(aurora_hip_model* mp, const aurora_hip_step_io* i
       m.arena.cap = m.arena.peak;
       m.generation += 1;
     }
+    // split-K tickets are trusted to be zero (gemm.hip): a step that did not return normally may have left counts behind
+    if (m.tickets_suspect)
+      hip_ok(hipMemsetAsync(m.tickets.p, 0, SPLIT_TICKETS * sizeof(int32_t), as_stream(stream)), "re-zeroing the split-K tickets");
+    m.tickets_suspect = true;
     run_step(m, s, stream);
+    m.tickets_suspect = false;
   })
 }
 

@@ -198,7 +198,10 @@ class Engine:
             at += n
         lat = self.native.full_lat()   # the whole (cropped) grid went through aurora_hip_precompute on every rank
         assert lat is not None and lat.shape[0] == H, "the full grid's latitudes are unknown to this rank"
-        return Batch(out[0], out[1], out[2], derive_metadata(pred.metadata, lat=lat.to(pred.metadata.lat)))
+        # (the caller's own full-grid static fields were not gathered: they are handed back as they came -- the next roll-out
+        # step, `_to_host` and `write_rollout` all read them from the prediction)
+        static = dict(full_static) if full_static is not None else out[1]
+        return Batch(out[0], static, out[2], derive_metadata(pred.metadata, lat=lat.to(pred.metadata.lat)))
 
     # -- per-launch timing (bench.py, tools): HIP events on the launch stream, inside the handle ---------------------
     def profile_start(self, only=None) -> None:

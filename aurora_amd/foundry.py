@@ -49,7 +49,7 @@ class Model(metaclass=abc.ABCMeta):
     @torch.inference_mode()
     def run(self, batch: Batch, num_steps: int) -> Generator[Batch, None, None]:
         """Perform `num_steps` prediction steps on the device; the predictions are yielded on the CPU."""
-        if next(self.model.parameters()).device.type != self.target_device.type:
+        if not _same_device(next(self.model.parameters()).device, self.target_device):
             self.model.to(self.target_device)   # in place, as upstream (a resident model stays where it is, engine and all)
         batch = batch.to(self.target_device)
         try:
@@ -57,6 +57,16 @@ class Model(metaclass=abc.ABCMeta):
         finally:
             if not self.keep_resident:
                 self.model.cpu()
+
+
+def _same_device(a: torch.device, b: torch.device) -> bool:
+    """Type AND index (an index of None means the current device): a model on cuda:1 is not on the target cuda:0."""
+    if a.type != b.type:
+        return False
+    if a.type != "cuda":
+        return True
+    cur = torch.cuda.current_device()
+    return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
 
 
 def _named(name: str, cls_name: str) -> type[Model]:

@@ -217,7 +217,9 @@ class Aurora(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         # .to() / .double() / .cuda() that really change storage drop the packed weights; a no-op `.to(device)` on a model
         # that is already there (foundry's `Model.run` does one per request) keeps the handle, its weights and workspace
-        stamp = lambda: [(p.data_ptr(), p.dtype, p.device) for p in self.parameters()]  # noqa: E731
+        # (buffers and in-place writes count too: `_version` moves when `fn` writes a tensor in place)
+        stamp = lambda: [(t.data_ptr(), t.dtype, t.device, t._version)  # noqa: E731
+                         for t in (*self.parameters(), *self.buffers())]
         before = stamp()
         out = super()._apply(fn, *args, **kwargs)
         if stamp() != before:

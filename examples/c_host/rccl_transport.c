@@ -4,7 +4,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 
 #define T_FAIL(t, ...)                                   \
   do {                                                   \
@@ -38,13 +40,19 @@ int rccl_transport_init(rccl_transport* t, int rank, int world, const char* id_f
     char tmp[4096];
     snprintf(tmp, sizeof tmp, "%s.tmp", id_file);
     FILE* f = fopen(tmp, "wb");
-    if (!f || fwrite(&id, sizeof id, 1, f) != 1) T_FAIL(t, "cannot write %.200s", tmp);
-    fclose(f);
-    if (rename(tmp, id_file) != 0) T_FAIL(t, "cannot rename %.200s", tmp);
+    if (!f) T_FAIL(t, "cannot write %.200s", tmp);
+    const size_t n = fwrite(&id, sizeof id, 1, f);
+    if (fclose(f) != 0 || n != 1) T_FAIL(t, "cannot write %.200s", tmp);
+    if (rename(tmp, id_file) != 0) T_FAIL(t, "cannot rename %.200s", tmp);   /* (replaces a stale file atomically) */
+    snprintf(t->id_file, sizeof t->id_file, "%s", id_file);                  /* removed again by rccl_transport_destroy */
   } else {
+    /* A file left behind by a run that crashed must not be taken for this run's: only a file written within the last
+     * `timeout_s` seconds counts (rank 0 of THIS run renames its file into place within that window or this rank gives up
+     * anyway), and rank 0 removes its file when it is done.  Launchers should still pass a path that is new per run. */
     const double t0 = now_s();
     for (;;) {
-      FILE* f = fopen(id_file, "rb");
+      struct stat st;
+      FILE* f = stat(id_file, &st) == 0 && difftime(time(NULL), st.st_mtime) <= timeout_s + 2.0 ? fopen(id_file, "rb") : NULL;
       if (f) {
         const size_t n = fread(&id, sizeof id, 1, f);
         fclose(f);
@@ -86,6 +94,8 @@ int rccl_transport_post(void* user, const aurora_hip_halo_msg* sends, int32_t n_
   for (int i = 0; i < n_recvs; ++i)
     if (recvs[i].offset < 0 || recvs[i].offset + recvs[i].bytes > t->staging_bytes || !peer_ok(t, recvs[i].peer))
       T_FAIL(t, "bad receive message %d (peer %d, %lld + %lld bytes)", i, recvs[i].peer, (long long)recvs[i].offset, (long long)recvs[i].bytes);
+  /* one event pair: correct only while post and wait strictly alternate (the step does: it waits before the next post) */
+  if (t->posted) T_FAIL(t, "post: the previous exchange has not been waited for (one exchange is in flight at a time)");
   T_HIP(t, hipEventRecord(t->ready, (hipStream_t)stream));
   T_HIP(t, hipStreamWaitEvent(t->side, t->ready, 0));
   T_NCCL(t, ncclGroupStart());
@@ -98,12 +108,15 @@ int rccl_transport_post(void* user, const aurora_hip_halo_msg* sends, int32_t n_
   T_NCCL(t, ncclGroupEnd());
   T_HIP(t, hipEventRecord(t->done, t->side));
   t->exchanges += 1;
+  t->posted = 1;
   return 0;
 }
 
 int rccl_transport_wait(void* user, void* stream) {
   rccl_transport* t = (rccl_transport*)user;
+  if (!t->posted) T_FAIL(t, "wait: no exchange was posted");
   T_HIP(t, hipStreamWaitEvent((hipStream_t)stream, t->done, 0));
+  t->posted = 0;
   return 0;
 }
 
@@ -151,5 +164,6 @@ void rccl_transport_destroy(rccl_transport* t) {
   if (t->done) (void)hipEventDestroy(t->done);
   if (t->side) (void)hipStreamDestroy(t->side);
   if (t->comm) (void)ncclCommDestroy(t->comm);
+  if (t->id_file[0]) (void)unlink(t->id_file);   /* rank 0: the next run must not find this run's id */
   memset(t, 0, sizeof *t);
 }

@@ -9,7 +9,8 @@
  *          every earlier reader of `recv`, are done before a byte moves); the group's sends / receives run on the side
  *          stream, so the rank's own qkv GEMM on the launch stream overlaps the transfer;
  *   wait:  the launch stream waits for the event recorded behind the group on the side stream.
- * One exchange is in flight at a time (the step calls wait before the next post), so one event pair suffices.
+ * One exchange is in flight at a time (the step calls wait before the next post), so one event pair suffices -- and ONLY
+ * then: post and wait must strictly alternate, which both callbacks check (`posted`) and refuse otherwise.
  */
 #ifndef AURORA_RCCL_TRANSPORT_H
 #define AURORA_RCCL_TRANSPORT_H
@@ -29,11 +30,15 @@ typedef struct rccl_transport {
   char* recv;
   int64_t staging_bytes;
   int64_t exchanges, bytes_sent;   /* counters for reports */
+  int posted;                /* an exchange is in flight: posted, not yet waited for */
+  char id_file[1024];        /* rank 0: the bootstrap file it wrote, removed again by rccl_transport_destroy */
   char error[256];           /* last failure, for the host's message (the callbacks only return -1) */
 } rccl_transport;
 
 /* Bootstrap without MPI: rank 0 creates the ncclUniqueId and writes it to `id_file` (atomically: temp file + rename), the
- * other ranks poll for the file (timeout_s seconds).  Then ncclCommInitRank.  The caller has selected its device. */
+ * other ranks poll for a file that is at most timeout_s seconds old (a file left by a crashed run is ignored; rank 0 removes
+ * its file in rccl_transport_destroy; pass a path that is new per run all the same).  Then ncclCommInitRank.  The caller
+ * has selected its device. */
 int rccl_transport_init(rccl_transport* t, int rank, int world, const char* id_file, double timeout_s);
 /* Allocates the two staging buffers (call after aurora_hip_precompute: aurora_hip_band_staging_bytes is known then). */
 int rccl_transport_allocate(rccl_transport* t, int64_t staging_bytes);

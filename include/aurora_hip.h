@@ -96,6 +96,11 @@ int aurora_hip_linear_batched(const void* A, int64_t lda, const void* W, int64_t
  *   aurora_hip_linear_workspace: bytes of scratch the library would like for this shape (0: it would not split).
  *   workspace, workspace_bytes : 16-byte aligned scratch, contents irrelevant; too small / NULL = no split.
  *   tickets, n_tickets         : int32 words, ZERO on entry and left zero (one per tile); fewer than tiles = no split.
+ *                                NOT validated: a count left behind by a launch that never finished (a device fault, a
+ *                                torn-down graph) means no workgroup of that tile ever draws its last ticket -- the tile's
+ *                                output rows are never written, silently.  Re-zero the words (hipMemsetAsync) after
+ *                                any failed launch; the model handle does so at the start of the step that follows a
+ *                                failed one.  Two launches that may run at the same time need their own ticket words.
  *   split                      : 0 lets the library choose, 1 forbids, > 1 asks for that many slices.
  * fp32 problems and shapes that would not split run exactly as aurora_hip_linear. */
 int64_t aurora_hip_linear_workspace(int64_t M, int N, int K, int dtype);

@@ -408,8 +408,9 @@ def test_linear_rejects_bad_k():
 # ------------------------------------------------------------------------------------------
 # window attention
 # ------------------------------------------------------------------------------------------
-def attention_reference(qkv, bias, tok, grp, B, Ltok, D, heads):
-    """Gather through the (already reference-checked) tables, SDPA per window, scatter back."""
+def attention_reference(qkv, bias, tok, grp, B, Ltok, D, heads, scaled_mask=False):
+    """Gather through the (already reference-checked) tables, SDPA per window, scatter back.  `scaled_mask`: the WRONG mask
+    -100 x (group difference) of an earlier build of the bf16 kernel, for the test that tells the two apart."""
     nW, N = tok.shape
     hd = D // heads
     out = torch.zeros((B, Ltok, D), dtype=torch.float64)
@@ -421,6 +422,8 @@ def attention_reference(qkv, bias, tok, grp, B, Ltok, D, heads):
         if grp is not None:
             g = torch.from_numpy(grp.astype(np.int64))
             mask = torch.where(g[:, None, :] != g[:, :, None], -100.0, 0.0)[:, None].double()
+            if scaled_mask:
+                mask = (-100.0 * (g[:, None, :] ^ g[:, :, None]))[:, None].double()
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
         o = o.transpose(1, 2).reshape(nW, N, D)
         valid = tok_t >= 0
@@ -453,6 +456,45 @@ def test_window_attention(res, window, heads, shifted, dtype):
     torch.cuda.synchronize()
     tol = 2e-5 if dtype == torch.float32 else 1.5e-2
     assert relerr(out.float(), ref) < tol
+
+
+@pytest.mark.parametrize("res,heads", [((4, 12, 24), 2), ((4, 13, 26), 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_window_attention_mask_is_the_references_literal_minus_100(res, heads, dtype):
+    """The shift mask is 0 / -100, NOT -inf (swin3d.py:357-358): a key of another group whose raw score
+    beats the query's own group by MORE than 100 still wins the softmax.  Adversarial inputs: the keys of one mask group
+    score 128 against every query (q . k / 8 with q_0 = 16, k_0 = 64), every other key about 0 -- queries of the other
+    groups then see those keys at 128 - 100 = 28 above their own group.  A mask of -100 x (group difference), or -inf, puts
+    the weight on the wrong keys; the reference is fp64 SDPA with the literal -100."""
+    from aurora_amd.engine import geometry
+
+    L = lib()
+    window, B, D = (2, 6, 12), 1, 64 * heads
+    Ltok = res[0] * res[1] * res[2]
+    tok, grp, _ = geometry.window_tables(res, window, True)
+    assert grp is not None
+    qkv = rnd(B, Ltok, 3, heads, 64, seed=31, scale=0.5)
+    # the loud keys: the tokens of the smallest group id != the first token's group in a window that mixes groups with a
+    # group difference >= 2 somewhere (where -100 x difference and -100 part ways)
+    mixed = [w for w in range(tok.shape[0]) if len(set(grp[w][tok[w] >= 0].tolist())) >= 2]
+    assert mixed and any((int(a) ^ int(b)) >= 2 for w in mixed for a in set(grp[w].tolist()) for b in set(grp[w].tolist()))
+    loud = np.zeros(Ltok, dtype=bool)
+    for w in mixed:
+        ids = sorted(set(grp[w][tok[w] >= 0].tolist()))
+        loud[tok[w][(grp[w] == ids[-1]) & (tok[w] >= 0)]] = True
+    qkv[:, :, 0, :, 0] = 16.0
+    qkv[:, :, 1, :, 0] = torch.where(torch.from_numpy(loud)[None, :, None], 64.0, 0.0).to(qkv.dtype)
+    qkv = qkv.reshape(B, Ltok, 3 * D).to(dtype)
+    bias = torch.zeros(3 * D)
+    ref = attention_reference(qkv.double(), bias.double(), tok, grp, B, Ltok, D, heads)
+    out = torch.full((B, Ltok, D), 7.0, dtype=dtype, device=DEV)
+    L.window_attention(qkv.to(DEV).contiguous(), bias.float().to(DEV), out, torch.from_numpy(tok).to(DEV),
+                       torch.from_numpy(grp).to(DEV), B, Ltok, D, heads)
+    torch.cuda.synchronize()
+    assert relerr(out.float(), ref) < (2e-5 if dtype == torch.float32 else 1.5e-2)
+    # the check has teeth: -100 x (group difference) gives something else on these inputs
+    wrong = attention_reference(qkv.double(), bias.double(), tok, grp, B, Ltok, D, heads, scaled_mask=True)
+    assert relerr(wrong, ref) > 0.1
 
 
 @pytest.mark.parametrize("M,heads,K", [(300, 2, 128), (1300, 8, 512), (70000, 8, 512), (2160, 32, 2048), (257, 4, 64)])
@@ -519,6 +561,28 @@ def test_layernorm_residual(D, dtype):
     torch.cuda.synchronize()
     assert relerr(out_f, ref) < 3e-6
     assert relerr(out_t.float(), ref) < (3e-6 if dtype == torch.float32 else 5e-3)
+
+
+@pytest.mark.parametrize("D", [256, 512, 1024, 2048])
+@pytest.mark.parametrize("M", [12001, 70003])
+def test_layernorm_many_rows_persistent_form(D, M):
+    """bf16 launches with many rows take the PERSISTENT kernel (csrc/norm.hip layernorm_bg_kernel: a fixed number of workgroups,
+    rows round-robin, so that it can run beside another stream's GEMM tiles): every row written exactly once, ragged row counts,
+    with and without gain / shift / residual / either output, in place on the residual stream as the backbone uses it."""
+    L = lib()
+    y = (rnd(M, D, seed=1, scale=3.0) + 0.5).bfloat16()
+    gain, shift, res = rnd(D, seed=2) + 1, rnd(D, seed=3), rnd(M, D, seed=4)
+    ref = F.layer_norm(y.double(), (D,), eps=1e-5) * gain + shift + res
+    x = res.float().to(DEV)                       # x <- x + LN(y) gain + shift, in place, plus the bf16 shadow
+    shadow = torch.zeros((M, D), dtype=torch.bfloat16, device=DEV)
+    L.layernorm(y.to(DEV), gain.float().to(DEV), shift.float().to(DEV), res=x, out_f32=x, out_t=shadow)
+    torch.cuda.synchronize()
+    assert relerr(x, ref) < 3e-6 and relerr(shadow.float(), ref) < 5e-3
+    assert torch.equal(shadow, x.bfloat16())
+    plain = torch.full((M, D), 9.0, dtype=torch.bfloat16, device=DEV)   # no gain / shift / residual, bf16 output only
+    L.layernorm(y.to(DEV), None, None, out_t=plain)
+    torch.cuda.synchronize()
+    assert relerr(plain.float(), F.layer_norm(y.double(), (D,), eps=1e-5)) < 5e-3
 
 
 def test_layernorm_in_place_on_column_block():

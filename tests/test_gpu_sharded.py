@@ -216,10 +216,18 @@ def _proc(rank, world, port, ret, tmp):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     model, batch = make("base_pad", False, 192, 96)
+    model_ref, _ = make("base_pad", False, 192, 96)    # an un-sharded twin (same seeded weights) for the roll-out reference
     with torch.inference_mode():
         ref = model.forward(batch) if rank == 0 else None
         model.configure_sharding(rank, world, gather_output=True)
         full = model.forward(batch)                       # every rank gets the whole prediction
+        # a gathered prediction carries the caller's static fields (the next roll-out step, `_to_host` and `write_rollout`
+        # read them from it), and a gathered roll-out runs more than one step
+        assert set(full.static_vars) == set(batch.static_vars)
+        assert all(torch.equal(full.static_vars[k].cpu(), v.cpu()) for k, v in batch.static_vars.items())
+        ref2 = list(aurora_amd.rollout(model_ref, batch, steps=2))[1] if rank == 0 else None
+        gathered2 = list(aurora_amd.rollout(model, batch, steps=2))[1]
+        assert not isinstance(gathered2, BandBatch) and set(gathered2.static_vars) == set(batch.static_vars)
         model.configure_sharding(rank, world, gather_output=False)
         preds = list(aurora_amd.rollout(model, batch, steps=2))  # state stays distributed
         # sharded output: every rank writes ITS band of every step, nothing is gathered
@@ -236,6 +244,7 @@ def _proc(rank, world, port, ret, tmp):
     if rank == 0:
         err = max(helpers.rel_err(full.atmos_vars[k].cpu(), v.cpu()) for k, v in ref.atmos_vars.items())
         err = max(err, max(helpers.rel_err(full.surf_vars[k].cpu(), v.cpu()) for k, v in ref.surf_vars.items()))
+        err = max(err, max(helpers.rel_err(gathered2.atmos_vars[k].cpu(), v.cpu()) for k, v in ref2.atmos_vars.items()))
         h0, h1 = preds[0].band
         P = model.patch_size
         err_band = max(helpers.rel_err(preds[0].atmos_vars[k].cpu(), v[..., h0 * P:h1 * P, :].cpu())
