@@ -214,13 +214,6 @@ struct aurora_hip_model {
   int fuse_ln = 1;
   bool split_attention = false;
   bool qkv_planes = true;   // bf16 blocks: q | k | v leave the qkv linear one attention head per plane (aurora_hip_linear_planes)
-  // Row chunks of the token-local half of a backbone block (step.hip): AURORA_ROW_CHUNKS (1 = one stream, no chunks),
-  // AURORA_CHUNK_SYNC (0 free-running, 1 staggered start, 2 chunk c one launch behind chunk c - 1), AURORA_CHUNK_MIN_ROWS
-  int row_chunks = 1, chunk_sync = 2;
-  int64_t chunk_min_rows = 4096;
-  std::vector<hipStream_t> side_streams;   // created on first use, on the device of the step
-  std::vector<hipEvent_t> sync_events;     // fork / join / stagger events of a step (timing disabled), re-used every step
-  size_t sync_next = 0;
 
   // per step
   aurora::DevBuf abs_enc, dyn_planes, ctx_max;
@@ -236,8 +229,6 @@ struct aurora_hip_model {
   ~aurora_hip_model() {
     for (auto& t : timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
     for (auto& e : event_pool) (void)hipEventDestroy(e);
-    for (auto& e : sync_events) (void)hipEventDestroy(e);
-    for (auto& st : side_streams) (void)hipStreamDestroy(st);
     for (auto& s : pinned) {
       if (s.host) (void)hipHostFree(s.host);
       if (s.done) (void)hipEventDestroy(s.done);
@@ -279,9 +270,6 @@ enum Kind { K_LINEAR_BF16, K_LINEAR_F32, K_WINDOW_ATTENTION, K_LAYERNORM, K_MERG
             K_PERCEIVER_ATTENTION, K_ASSEMBLE, K_UNPATCHIFY, K_COPY2D, K_ABSMAX, K_LINEAR_LN, K_GATHER, K_COUNT };
 
 hipEvent_t take_event(Model& m);
-// side stream `i` (>= 1) of the handle and the next fork / join event of the step (model.hip)
-hipStream_t side_stream(Model& m, int i);
-hipEvent_t sync_event(Model& m);
 
 // Runs `fn` (one launch), bracketed by an event pair when this kind is being profiled.
 template <typename F>
@@ -307,7 +295,6 @@ constexpr int SPLIT_TICKETS = 4096;
 struct Launcher {
   Model& m;
   void* stream;
-  bool no_ws = false;   // launches of a row chunk: other streams are running, nothing may be borrowed from the arena's top
   // batch > 1: `batch` strided problems in one launch (aurora_hip_linear_batched); strides in elements
   void linear(const void* A, int64_t lda, const void* Wt, int64_t ldw, const float* bias, void* C, int64_t ldc, int64_t M,
               int N, int K, int dtype, int act = AURORA_ACT_NONE, void* C2 = nullptr, int64_t ldc2 = 0,
@@ -317,7 +304,7 @@ struct Launcher {
     void* ws = nullptr;
     int64_t ws_bytes = 0;
     const size_t mark = m.arena.top;
-    if (!no_ws && m.split_k && dtype == AURORA_BF16 && batch == 1 && f32_gemm == -1 && (ws_bytes = aurora_hip_linear_workspace(M, N, K, dtype)) > 0)
+    if (m.split_k && dtype == AURORA_BF16 && batch == 1 && f32_gemm == -1 && (ws_bytes = aurora_hip_linear_workspace(M, N, K, dtype)) > 0)
       ws = m.arena.take((size_t)ws_bytes);
     timed(m, stream, dtype == AURORA_BF16 ? K_LINEAR_BF16 : K_LINEAR_F32, 2.0 * (double)M * N * K * batch, [&] {
       if (ws)

@@ -142,24 +142,6 @@ hipEvent_t take_event(Model& m) {
   return e;
 }
 
-hipStream_t side_stream(Model& m, int i) {
-  while ((int)m.side_streams.size() < i) {
-    hipStream_t st;
-    hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
-    m.side_streams.push_back(st);
-  }
-  return m.side_streams[i - 1];
-}
-
-hipEvent_t sync_event(Model& m) {
-  if (m.sync_next == m.sync_events.size()) {
-    hipEvent_t e;
-    hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-    m.sync_events.push_back(e);
-  }
-  return m.sync_events[m.sync_next++];
-}
-
 int bounded_mode() {
   static const int mode = getenv("AURORA_F32_GEMM") ? -1 : 2;
   return mode;
@@ -670,9 +652,6 @@ extern "C" int aurora_hip_create(const aurora_hip_config* c, aurora_hip_model** 
     if (const char* e = getenv("AURORA_BAND_SPLIT_ATTENTION")) m->split_attention = atoi(e) != 0;
     if (const char* e = getenv("AURORA_QKV_PLANES")) m->qkv_planes = atoi(e) != 0;
     if (const char* e = getenv("AURORA_SPLIT_K")) m->split_k = atoi(e) != 0;
-    if (const char* e = getenv("AURORA_ROW_CHUNKS")) m->row_chunks = std::min(4, std::max(1, atoi(e)));
-    if (const char* e = getenv("AURORA_CHUNK_SYNC")) m->chunk_sync = atoi(e);
-    if (const char* e = getenv("AURORA_CHUNK_MIN_ROWS")) m->chunk_min_rows = std::max(256, atoi(e));
     m->tickets = DevBuf(SPLIT_TICKETS * sizeof(int32_t));
     hip_ok(hipMemset(m->tickets.p, 0, SPLIT_TICKETS * sizeof(int32_t)), "hipMemset");
     *out = m.release();

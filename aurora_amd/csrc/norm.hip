@@ -7,8 +7,6 @@
 // two-pass fp32 (mean, then centred second moment) reduced with xor-shuffles.  4 rows per block.
 #include <stdlib.h>
 
-#include <algorithm>
-
 #include "common.h"
 
 namespace aurora {
@@ -145,100 +143,6 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
       } else if (p.out_t) {
         store4(reinterpret_cast<T*>(p.out_t) + row * p.ldt + e, o);
       }
-    }
-  }
-}
-
-// The bf16 LayerNorm in a form that runs BESIDE a GEMM workgroup on the same CU (profiles/r05_coreside_probe.log).
-// The ping-pong GEMM holds 2 waves x 208 VGPRs per SIMD and 128 KiB of LDS: 96 VGPRs per SIMD, 32 KiB of LDS and six wave
-// slots stay free on a CU it occupies.  One-row-per-wave launches of ~16,000 small workgroups cannot use that room: they
-// take every CU a finished tile frees and keep it until the launch is over (a new tile needs the whole CU back).  This kernel
-// is PERSISTENT -- a fixed number of workgroups (4 waves, <= 96 VGPRs each), rows taken round-robin, y and the residual row
-// requested together -- so it never holds more than it started with, and a GEMM tile of another stream always finds its
-// registers beside it: the LayerNorm's HBM traffic then runs under the GEMM's matrix work instead of in front of it.
-// Alone it streams at the one-row-per-wave kernel's rate (5.25 vs 5.43 TB/s at 64,800 x 1024).
-// Rows of up to 2048 features (beyond 1024 the residual row is requested behind the statistics: registers).
-// Sum over the 64 lanes without the LDS crossbar (ds_bpermute shares the LDS pipe with the GEMM workgroup next door, and its
-// six lane-index registers count against the 96 this kernel may hold): half / row swaps (v_permlane32_swap,
-// v_permlane16_swap), then rotations inside a row of 16 lanes by DPP.
-__device__ __forceinline__ float wave_sum_valu(float v) {
-  typedef unsigned u32x2_sw __attribute__((ext_vector_type(2)));
-  u32x2_sw r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(r.x) + __uint_as_float(r.y);
-  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(r.x) + __uint_as_float(r.y);
-  v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128, 0xf, 0xf, true));   // row_ror:8
-  v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x124, 0xf, 0xf, true));   // row_ror:4
-  v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x122, 0xf, 0xf, true));   // row_ror:2
-  v += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x121, 0xf, 0xf, true));   // row_ror:1
-  return v;
-}
-
-template <int NC, bool PRE>   // chunks of 256 features; PRE: the residual row is requested together with y
-__global__ __launch_bounds__(256) void layernorm_bg_kernel(const LnArgs p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t n_waves = (int64_t)gridDim.x * ROWS_PER_BLOCK;
-  const int n_pieces = p.D >> 2;
-  const float inv_d = 1.0f / p.D;
-  // (the row is uniform over the wave: said explicitly, row pointers live in scalar registers and a lane keeps ONE offset)
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; row < p.M; row += n_waves) {
-    const bf16_t* yr = reinterpret_cast<const bf16_t*>(p.y) + row * p.ldy;
-    const float* rr = p.res ? p.res + row * p.ldr : nullptr;   // (no `res_mod`: those launches keep the one-row-per-wave kernel)
-    float v[NC][4], r4[PRE ? NC : 1][4];
-#pragma unroll
-    for (int i = 0; i < NC; ++i)
-      if (lane + 64 * i < n_pieces) {
-        load4(yr + (lane + 64 * i) * 4, v[i]);
-        if constexpr (PRE) {
-          if (rr) load4(rr + (lane + 64 * i) * 4, r4[i]);
-        }
-      }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; ++i)
-      if (lane + 64 * i < n_pieces) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mean = wave_sum_valu(s) * inv_d;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; ++i)
-      if (lane + 64 * i < n_pieces) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float d = v[i][j] - mean;
-          q = fmaf(d, d, q);
-        }
-      }
-    const float rstd = rsqrtf(wave_sum_valu(q) * inv_d + p.eps);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-      const int e = (lane + 64 * i) * 4;
-      if (lane + 64 * i < n_pieces) {
-        float gn[4], sh[4], o[4];
-        if (p.gain) load4(p.gain + e, gn);
-        if (p.shift) load4(p.shift + e, sh);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float t = (v[i][j] - mean) * rstd;
-          if (p.gain) t *= gn[j];
-          if (p.shift) t += sh[j];
-          o[j] = t;
-        }
-        if (rr) {
-          if constexpr (PRE) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += r4[i][j];
-          } else {
-            float r[4];
-            load4(rr + e, r);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] += r[j];
-          }
-        }
-        if (p.out_f32) store4(p.out_f32 + row * p.ldo + e, o);
-        if (p.out_t) store4(reinterpret_cast<bf16_t*>(p.out_t) + row * p.ldt + e, o);
-      }
-      __builtin_amdgcn_sched_barrier(0);   // (keeps the gain / shift loads of later chunks from being hoisted: registers)
     }
   }
 }
@@ -399,15 +303,7 @@ static int layernorm_impl(const void* y, int64_t ldy, const float* gain, const f
     // (A/B inside the step, profiles/r04_ab_gn_lnprefetch_instep.log: forced on everywhere LayerNorm 11.2 -> 11.4 ms per
     // un-sharded step -- twice the registers halve the waves of the big launches --, on a rank of eight 3.05 -> 2.86 ms)
     const bool pre = res != nullptr && M <= (int64_t)40 * device_cus();   // (16,200 rows, the un-sharded stage 2: 74.5 -> 79.0 us with it)
-    // many rows: the persistent form that can run beside another stream's GEMM tiles (above); AURORA_LN_BG=0: one row per wave
-    static const bool bg_on = !(getenv("AURORA_LN_BG") && atoi(getenv("AURORA_LN_BG")) == 0);   // (read once; an A/B switch)
-    if (!pre && bg_on && D <= 2048 && res_mod == 0) {
-      const dim3 gbg((unsigned)std::min<int64_t>(row_blocks(M), (int64_t)4 * device_cus()));
-      if (D <= 256) hipLaunchKernelGGL((layernorm_bg_kernel<1, true>), gbg, block, 0, as_stream(stream), p);
-      else if (D <= 512) hipLaunchKernelGGL((layernorm_bg_kernel<2, true>), gbg, block, 0, as_stream(stream), p);
-      else if (D <= 1024) hipLaunchKernelGGL((layernorm_bg_kernel<4, true>), gbg, block, 0, as_stream(stream), p);
-      else hipLaunchKernelGGL((layernorm_bg_kernel<8, false>), gbg, block, 0, as_stream(stream), p);
-    } else if (pre) {
+    if (pre) {
       if (D <= 256) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 1, true>), grid, block, 0, as_stream(stream), p);
       else if (D <= 512) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 2, true>), grid, block, 0, as_stream(stream), p);
       else if (D <= 1024) hipLaunchKernelGGL((layernorm_f32_kernel<bf16_t, 4, true>), grid, block, 0, as_stream(stream), p);

@@ -217,7 +217,6 @@ void run_step(Model& m, const StepIO& s, void* stream) {
   // chain, 1: atmospheric / 2: surface patch-embedding inputs, 3: decoder context), cleared by ONE launch; their producers
   // fold the maxima in (patchify) or scan (absmax_fold)
   if (!m.dry) ok(aurora_hip_zero_words(m.ctx_max.f(), 4, stream));
-  m.sync_next = 0;
   // ================= encoder (encoder.py:198-366) =================
   float* x_f = (float*)A.take((size_t)B * Cl * Lp * D * 4);                      // residual stream of stage 0 (fp32)
   void* x_b = m.autocast ? A.take((size_t)B * Cl * Lp * D * 2) : nullptr;        // bf16 shadow (GEMM operand)
@@ -346,40 +345,9 @@ void run_step(Model& m, const StepIO& s, void* stream) {
   const int64_t L0 = (int64_t)Cl * Lp;
   float* x_cat = (float*)A.take((size_t)B * L0 * 2 * D * 4);
 
-  // fork / join of the row-chunk streams (below): plain event edges, so a captured step becomes a graph with parallel branches
-  auto edge = [&](void* from, void* to) {
-    hipEvent_t e = sync_event(m);
-    hip_ok(hipEventRecord(e, (hipStream_t)from), "hipEventRecord");
-    hip_ok(hipStreamWaitEvent((hipStream_t)to, e, 0), "hipStreamWaitEvent");
-  };
-
   auto run_blocks = [&](int count, float* xf, void* xb, int stage, float* final_out, int64_t final_ld) {
     const Res res = local_res(stage);
     const int64_t Ls = (int64_t)res.c * res.h * res.w, M = (int64_t)B * Ls;
-    // ROW CHUNKS.  Behind the attention a block is token-local: proj -> AdaLN + residual -> fc1 -> fc2 -> AdaLN + residual
-    // (swin3d.py:507-508, 59-66) -- and so is the qkv linear of the NEXT block (swin3d.py:153).  The rows are cut into
-    // `nck` tile-aligned chunks, one HIP stream each, chunk c one launch behind chunk c - 1: while one chunk's LayerNorm
-    // (HBM-bound, matrix pipe idle) runs, the other chunk's GEMM (MFMA-bound, HBM idle) has the rest of the chip, and a
-    // GEMM's last, partly filled round of tiles is topped up by the other stream's workgroups.  No halo, no extra FLOPs:
-    // the same launches over half the rows each.  One fork after the attention, one join in front of the next one.
-    const int nck = (m.row_chunks > 1 && M / m.row_chunks >= m.chunk_min_rows) ? m.row_chunks : 1;
-    std::vector<Launcher> LS;
-    std::vector<int64_t> row0(nck + 1, M);
-    for (int c = 0; c < nck; ++c) {
-      LS.push_back(Launcher{m, c == 0 ? stream : (m.dry ? nullptr : (void*)side_stream(m, c)), nck > 1});
-      row0[c] = M * c / nck / 256 * 256;
-    }
-    bool forked = false, qkv_ready = false;
-    auto fork = [&] {
-      if (nck == 1 || m.dry) return;
-      for (int c = 1; c < nck; ++c) edge(stream, LS[c].stream);
-      forked = true;
-    };
-    auto join = [&] {
-      if (!forked) return;
-      for (int c = 1; c < nck; ++c) edge(LS[c].stream, stream);
-      forked = false;
-    };
     for (int k = 0; k < count; ++k, ++bi) {
       const Block& blk = m.blocks[bi];
       const int dim = blk.dim;
@@ -399,34 +367,16 @@ void run_step(Model& m, const StepIO& s, void* stream) {
                                                     n_tok, bb, stream);
         });
       };
-      // D = 512 under autocast: the linear, its AdaLN and the residual add are ONE launch (a workgroup owns whole rows)
-      // m.fuse_ln (AURORA_FUSE_LN when the handle was created): 0 never, 1 (default) by the fill rule below, 2 always
-      const int fuse_env = m.fuse_ln;
-      // (a row-owning tile is 128 rows: only when the launch fills its rounds of one tile per CU -- a latitude band's
-      // 270 tiles on 256 CUs would take two rounds for the work of 1.05; chunks on concurrent streams fill each other's rounds)
-      const int64_t ln_tiles = (M + 127) / 128, cus = device_cus();
-      const bool fills = (double)ln_tiles >= 0.85 * (double)(((ln_tiles + cus - 1) / cus) * cus);
-      const bool fuse = bf && dim == 512 && (fuse_env == 2 || (fuse_env == 1 && fills));
-      // In chunk mode nothing of a block may share memory with anything else of it (chunks are at different launches of
-      // the chain at the same time): q | k | v, the attention output, the linear results in front of the LayerNorms and
-      // the MLP's hidden layer are four buffers -- the same four for every block of the stage.
-      void *qkv_c = nullptr, *y_c = nullptr, *hid_c = nullptr;
-      const bool last = final_out != nullptr && k == count - 1;
-      join();   // (the previous block's chunks)
       if (!sharded) {
         void* qkv = A.take((size_t)M * 3 * dim * es);
-        if (planes) plane_stride = M * 192;
-        ao = A.take((size_t)M * dim * es);
-        if (nck > 1) {
-          y_c = fuse ? nullptr : A.take((size_t)M * dim * es);
-          hid_c = A.take((size_t)M * blk.hidden * es);
-          qkv_c = qkv;
-        }
-        if (!qkv_ready) {   // (else: the previous block's chunks wrote it, each its own rows)
-          if (planes) L.linear_planes(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, plane_stride, blk.heads, M, 3 * dim, dim);
-          else L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
+        if (planes) {
+          plane_stride = M * 192;
+          L.linear_planes(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, plane_stride, blk.heads, M, 3 * dim, dim);
+        } else {
+          L.linear(a_in, dim, aw.qkv[bi], dim, blk.qkv_b, qkv, 3 * dim, M, 3 * dim, dim, bb);
         }
         const DevTables& tb = tables_for(m, stage, blk.shifted);
+        ao = A.take((size_t)M * dim * es);
         attend(qkv, (const int32_t*)tb.tok.p, tb.has_grp ? (const uint8_t*)tb.grp.p : nullptr, tb.n_windows, tb.n_tok, Ls, Ls);
       } else {
         // A band: the attention table indexes [own rows | halo rows]; outputs are written for owned tokens only.
@@ -437,10 +387,6 @@ void run_step(Model& m, const StepIO& s, void* stream) {
         REQUIRE(!planes || B == 1, "a latitude band runs one batch element");
         if (planes) plane_stride = Lq * 192;
         ao = A.take((size_t)M * dim * es);
-        if (nck > 1) {
-          y_c = fuse ? nullptr : A.take((size_t)M * dim * es);
-          hid_c = A.take((size_t)M * blk.hidden * es);
-        }
         const int32_t* tok = (const int32_t*)pl.tok.p;
         const uint8_t* grp = pl.has_grp ? (const uint8_t*)pl.grp.p : nullptr;
         const bool exchange = pl.n_halo > 0 || pl.send_cnt[0] > 0 || pl.send_cnt[1] > 0;
@@ -503,98 +449,42 @@ void run_step(Model& m, const StepIO& s, void* stream) {
           attend(qkv, tok, grp, pl.n_windows, pl.n_tok, Lq, Ls);
         }
       }
-      // rows [r0, r0 + nr) of x <- x + LN(A W^T + b) gain + shift, one launch on `st`
-      auto fused = [&](void* st, const void* a, const void* w, const float* bias, int K_, const float* gain, const float* shift,
-                       int64_t r0, int64_t nr, float* xo, int64_t ldo, void* xbo) {
-        timed(m, st, K_LINEAR_LN, 2.0 * (double)nr * dim * K_, [&] {
-          return aurora_hip_linear_layernorm((const char*)a + (size_t)r0 * K_ * es, K_, w, K_, bias, gain, shift, xf + (size_t)r0 * dim, dim,
-                                             xo + (size_t)r0 * ldo, ldo, xbo ? (char*)xbo + (size_t)r0 * dim * es : nullptr, dim, nr, dim,
-                                             K_, 1e-5f, st);
+      // D = 512 under autocast: the linear, its AdaLN and the residual add are ONE launch (a workgroup owns whole rows)
+      // m.fuse_ln (AURORA_FUSE_LN when the handle was created): 0 never, 1 (default) by the fill rule below, 2 always
+      const int fuse_env = m.fuse_ln;
+      // (a row-owning tile is 128 rows: only when the launch fills its rounds of one tile per CU -- a latitude band's
+      // 270 tiles on 256 CUs would take two rounds for the work of 1.05)
+      const int64_t ln_tiles = (M + 127) / 128, cus = device_cus();
+      const bool fills = (double)ln_tiles >= 0.85 * (double)(((ln_tiles + cus - 1) / cus) * cus);
+      const bool fuse = bf && dim == 512 && (fuse_env == 2 || (fuse_env == 1 && fills));
+      auto fused = [&](const void* a, const void* w, const float* bias, int K_, const float* gain, const float* shift, float* xo,
+                       int64_t ldo, void* xbo) {
+        timed(m, stream, K_LINEAR_LN, 2.0 * (double)M * dim * K_, [&] {
+          return aurora_hip_linear_layernorm(a, K_, w, K_, bias, gain, shift, xf, dim, xo, ldo, xbo, dim, M, dim, K_, 1e-5f, stream);
         });
       };
-      if (nck == 1) {
-        if (fuse) {
-          fused(stream, ao, aw.proj[bi], blk.proj_b, dim, blk.gain1, blk.shift1, 0, M, xf, dim, xb);
-        } else {
-          void* y = A.take((size_t)M * dim * es);
-          L.linear(ao, dim, aw.proj[bi], dim, blk.proj_b, y, dim, M, dim, dim, bb);
-          L.layernorm(y, dim, blk.gain1, blk.shift1, xf, dim, 0, xf, dim, xb, dim, M, dim, 1e-5f, bb);
-        }
-        A.top = mark;
-        void* hid = A.take((size_t)M * blk.hidden * es);
-        L.linear(a_in, dim, blk.fc1_w, dim, blk.fc1_b, hid, blk.hidden, M, blk.hidden, dim, bb, AURORA_ACT_GELU);
-        if (fuse) {
-          fused(stream, hid, blk.fc2_w, blk.fc2_b, blk.hidden, blk.gain2, blk.shift2, 0, M, last ? final_out : xf, last ? final_ld : dim,
-                last ? nullptr : xb);
-        } else {
-          void* y2 = A.take((size_t)M * dim * es);
-          L.linear(hid, blk.hidden, blk.fc2_w, blk.hidden, blk.fc2_b, y2, dim, M, dim, blk.hidden, bb);
-          L.layernorm(y2, dim, blk.gain2, blk.shift2, xf, dim, 0, last ? final_out : xf, last ? final_ld : dim, last ? nullptr : xb,
-                      dim, M, dim, 1e-5f, bb);
-        }
-        A.top = mark;
-        continue;
+      if (fuse) {
+        fused(ao, aw.proj[bi], blk.proj_b, dim, blk.gain1, blk.shift1, xf, dim, xb);
+      } else {
+        void* y = A.take((size_t)M * dim * es);
+        L.linear(ao, dim, aw.proj[bi], dim, blk.proj_b, y, dim, M, dim, dim, bb);
+        L.layernorm(y, dim, blk.gain1, blk.shift1, xf, dim, 0, xf, dim, xb, dim, M, dim, 1e-5f, bb);
       }
-      // ---- the token-local half in row chunks ----
-      const bool q_next = !sharded && k + 1 < count;   // (a band's next block may send halo rows first: its qkv stays whole)
-      auto row = [&](const void* p, int64_t r, int64_t ld, size_t elt) { return (char*)p + (size_t)r * ld * elt; };
-      auto op = [&](int i, int c) {
-        Launcher& Lc = LS[c];
-        const int64_t r0 = row0[c], nr = row0[c + 1] - r0;
-        float* xf_r = xf + (size_t)r0 * dim;
-        void* xb_r = xb ? row(xb, r0, dim, 2) : nullptr;
-        float* out_r = last ? final_out + (size_t)r0 * final_ld : xf_r;
-        switch (i) {
-          case 0:   // proj (+ AdaLN + residual)
-            if (fuse) fused(Lc.stream, ao, aw.proj[bi], blk.proj_b, dim, blk.gain1, blk.shift1, r0, nr, xf, dim, xb);
-            else Lc.linear(row(ao, r0, dim, es), dim, aw.proj[bi], dim, blk.proj_b, row(y_c, r0, dim, es), dim, nr, dim, dim, bb);
-            break;
-          case 1:
-            Lc.layernorm(row(y_c, r0, dim, es), dim, blk.gain1, blk.shift1, xf_r, dim, 0, xf_r, dim, xb_r, dim, nr, dim, 1e-5f, bb);
-            break;
-          case 2:
-            Lc.linear(bf ? xb_r : (void*)xf_r, dim, blk.fc1_w, dim, blk.fc1_b, row(hid_c, r0, blk.hidden, es), blk.hidden, nr, blk.hidden,
-                      dim, bb, AURORA_ACT_GELU);
-            break;
-          case 3:   // fc2 (+ AdaLN + residual)
-            if (fuse)
-              fused(Lc.stream, hid_c, blk.fc2_w, blk.fc2_b, blk.hidden, blk.gain2, blk.shift2, r0, nr, last ? final_out : xf,
-                    last ? final_ld : dim, last ? nullptr : xb);
-            else
-              Lc.linear(row(hid_c, r0, blk.hidden, es), blk.hidden, blk.fc2_w, blk.hidden, blk.fc2_b, row(y_c, r0, dim, es), dim, nr, dim,
-                        blk.hidden, bb);
-            break;
-          case 4:
-            Lc.layernorm(row(y_c, r0, dim, es), dim, blk.gain2, blk.shift2, xf_r, dim, 0, out_r, last ? final_ld : dim,
-                         last ? nullptr : xb_r, dim, nr, dim, 1e-5f, bb);
-            break;
-          case 5: {   // q | k | v of the next block, this chunk's rows
-            const Block& nb = m.blocks[bi + 1];
-            if (planes)
-              Lc.linear_planes(bf ? xb_r : (void*)xf_r, dim, aw.qkv[bi + 1], dim, nb.qkv_b, row(qkv_c, r0, 192, es), plane_stride, nb.heads,
-                               nr, 3 * dim, dim);
-            else
-              Lc.linear(bf ? xb_r : (void*)xf_r, dim, aw.qkv[bi + 1], dim, nb.qkv_b, row(qkv_c, r0, 3 * dim, es), 3 * dim, nr, 3 * dim, dim,
-                        bb);
-            break;
-          }
-        }
-      };
-      fork();
-      for (int i = 0; i < 6; ++i) {
-        if ((fuse && (i == 1 || i == 4)) || (i == 5 && !q_next)) continue;
-        for (int c = 0; c < nck; ++c) {
-          // chunk c runs launch i only when chunk c - 1 has finished ITS launch i: one launch behind, so that the chunks are
-          // in different kernels of the chain at any time (sync 1: only the start is staggered; 0: free-running)
-          const bool staggered = !m.dry && (m.chunk_sync == 2 || (m.chunk_sync == 1 && i == 0));
-          op(i, c);
-          if (staggered && c + 1 < nck) edge(LS[c].stream, LS[c + 1].stream);
-        }
+      A.top = mark;
+      void* hid = A.take((size_t)M * blk.hidden * es);
+      L.linear(a_in, dim, blk.fc1_w, dim, blk.fc1_b, hid, blk.hidden, M, blk.hidden, dim, bb, AURORA_ACT_GELU);
+      const bool last = final_out != nullptr && k == count - 1;
+      if (fuse) {
+        fused(hid, blk.fc2_w, blk.fc2_b, blk.hidden, blk.gain2, blk.shift2, last ? final_out : xf, last ? final_ld : dim,
+              last ? nullptr : xb);
+      } else {
+        void* y2 = A.take((size_t)M * dim * es);
+        L.linear(hid, blk.hidden, blk.fc2_w, blk.hidden, blk.fc2_b, y2, dim, M, dim, blk.hidden, bb);
+        L.layernorm(y2, dim, blk.gain2, blk.shift2, xf, dim, 0, last ? final_out : xf, last ? final_ld : dim, last ? nullptr : xb,
+                    dim, M, dim, 1e-5f, bb);
       }
-      qkv_ready = q_next;
       A.top = mark;
     }
-    join();
   };
 
   float* xf = x_f;

@@ -491,7 +491,10 @@ def test_window_attention_mask_is_the_references_literal_minus_100(res, heads, d
     L.window_attention(qkv.to(DEV).contiguous(), bias.float().to(DEV), out, torch.from_numpy(tok).to(DEV),
                        torch.from_numpy(grp).to(DEV), B, Ltok, D, heads)
     torch.cuda.synchronize()
-    assert relerr(out.float(), ref) < (2e-5 if dtype == torch.float32 else 1.5e-2)
+    # (fp32: a score of 128 carries an absolute rounding error of ~128 x 2^-23, which the exponential turns into a relative
+    # error of the weights -- ten times the tolerance of the ordinary cases, four orders below what the wrong mask does)
+    err = relerr(out.float(), ref)
+    assert err < (2e-4 if dtype == torch.float32 else 1.5e-2), err
     # the check has teeth: -100 x (group difference) gives something else on these inputs
     wrong = attention_reference(qkv.double(), bias.double(), tok, grp, B, Ltok, D, heads, scaled_mask=True)
     assert relerr(wrong, ref) > 0.1
@@ -565,10 +568,11 @@ def test_layernorm_residual(D, dtype):
 
 @pytest.mark.parametrize("D", [256, 512, 1024, 2048])
 @pytest.mark.parametrize("M", [12001, 70003])
-def test_layernorm_many_rows_persistent_form(D, M):
-    """bf16 launches with many rows take the PERSISTENT kernel (csrc/norm.hip layernorm_bg_kernel: a fixed number of workgroups,
-    rows round-robin, so that it can run beside another stream's GEMM tiles): every row written exactly once, ragged row counts,
-    with and without gain / shift / residual / either output, in place on the residual stream as the backbone uses it."""
+def test_layernorm_many_rows(D, M):
+    """bf16 launches with tens of thousands of rows, as the backbone issues them (the small-M cases above take the variant
+    that prefetches the residual row): every row written exactly once, ragged row counts, with and without gain / shift /
+    residual / either output, in place on the residual stream.  (Round 5 also ran this against a persistent, grid-stride
+    form of the kernel, built to co-reside with another stream's GEMM tiles and deleted again: profiles/README.md.)"""
     L = lib()
     y = (rnd(M, D, seed=1, scale=3.0) + 0.5).bfloat16()
     gain, shift, res = rnd(D, seed=2) + 1, rnd(D, seed=3), rnd(M, D, seed=4)
