@@ -420,7 +420,7 @@ def main() -> None:
         # `traffic_build` names the commit whose library those passes profiled.
         traffic, traffic_build = None, None
         pmc = sorted((ROOT / "profiles").glob("r*_pmc_summary.json"))
-        traffic_stale = None
+        traffic_stale, stale_sources = None, None
         if pmc:
             import hashlib
 
@@ -432,6 +432,11 @@ def main() -> None:
             traffic_stale = pj.get("gemm_source_sha256") != sha
             if traffic_stale:
                 traffic = None
+            # every kernel source, not only the GEMM's: which of the profiled files differ from the tree (their rows in the
+            # committed rNN_kernel_stats.txt / rNN_pmc_summary.json describe an earlier build)
+            stale_sources = sorted(n for n, d in (pj.get("source_sha256") or {}).items()
+                                   if n != "libaurora_hip.so" and (not (ROOT / "aurora_amd" / "csrc" / n).exists() or
+                                   hashlib.sha256((ROOT / "aurora_amd" / "csrc" / n).read_bytes()).hexdigest() != d))
         per = max(args.steps, 1)
         out = {
             "metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13",
@@ -454,7 +459,7 @@ def main() -> None:
                 "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": traffic,
                 "traffic_source": f"profiles/{pmc[-1].name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command; "
                                   "2 x FETCH_SIZE per profiles/r02_fetch_calibration.txt)" if pmc else None,
-                "traffic_build": traffic_build, "traffic_stale": traffic_stale,
+                "traffic_build": traffic_build, "traffic_stale": traffic_stale, "profile_stale_sources": stale_sources,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_GEMM_LAUNCH,
                 "launches_per_step": g["launches"] / per, "ms_per_step": g["ms"] / per,
                 "frac_all_matrix_launches": all_tf / PEAK_BF16_TFLOPS,

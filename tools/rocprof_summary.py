@@ -7,6 +7,7 @@ import sys
 
 db_path, out_path = sys.argv[1], sys.argv[2]
 cmd = sys.argv[3] if len(sys.argv) > 3 else ""
+sources = open(sys.argv[4]).read().splitlines() if len(sys.argv) > 4 else []   # `sha256sum` lines of what was profiled
 cur = sqlite3.connect(db_path).cursor()
 rows = cur.execute(
     "select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, "
@@ -15,6 +16,8 @@ rows = cur.execute(
 total = sum(r[2] for r in rows)
 with open(out_path, "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats summary\n# command: {cmd}\n# total kernel time {total:.2f} ms\n")
+    for line in sources:   # the build these rows describe (tools/profile_round.sh)
+        f.write(f"# sha256 {line}\n")
     f.write(f"{'total_ms':>10} {'pct':>6} {'calls':>6} {'avg_us':>10} {'min_us':>9} {'max_us':>10} {'vgpr':>5} {'agpr':>5} {'lds':>7}  kernel\n")
     for name, n, ms, avg, mn, mx, vg, ag, lds in rows:
         if ms / total < 0.0005:
