@@ -25,7 +25,7 @@ One JSON line on stdout (rank 0), with two extra objects:
   cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/aurora_oracle.py) timed on this box's host
                 cores on the SAME workload: the full 720 x 1440 grid, the same seeded weights and Batch as the GPU step
                 (a 1/16 sub-grid is timed first as a fall-back should the full grid not finish in its budget); plus
-                the real reference's full-grid timing measured in the build container (profiles/r02_reference_cpu.json).
+                the real reference's full-grid timing measured in the build container (profiles/r05_reference_cpu.json).
   parity_full_grid   the outputs of that oracle run against the GPU step's, per variable mean|out-ref| / mean|ref|
                 (the metric of the reference's tests/test_model.py:45-61): the fp32 engine must stay below 1e-4, the
                 bf16 (autocast) engine below 5e-3 -- the bench exits non-zero otherwise.
@@ -492,7 +492,10 @@ def main() -> None:
             # The real reference (microsoft/aurora itself) cannot run on this box (no /root/reference here): its
             # timing, and the port's on the same machine and inputs, come from tools/time_reference.py in the build
             # container (tracked file, full 721 x 1440 grid).
-            ref = ROOT / "profiles" / "r02_reference_cpu.json"
+            # (the latest record: round 5 re-timed both on an IDLE container -- 206 s, BASELINE.md's 201 s; round 2's 462 s was
+            # taken while the container was compiling)
+            refs = sorted((ROOT / "profiles").glob("r*_reference_cpu.json"))
+            ref = refs[-1] if refs else ROOT / "profiles" / "r02_reference_cpu.json"
             if ref.exists():
                 r = json.loads(ref.read_text())
                 out["cpu_baseline"]["reference_measured_elsewhere"] = {
@@ -500,7 +503,7 @@ def main() -> None:
                     "kind": "reference", "port_over_reference_time": r.get("port_over_reference_time"),
                     "sample": f"microsoft/aurora AuroraPretrained fp32, full {r['grid'][0]}x{r['grid'][1]} grid, one "
                               f"forward in {r['reference_s_per_step']:.0f} s on the build container's {r['threads']} cores "
-                              "(tools/time_reference.py)"}
+                              f"(tools/time_reference.py, profiles/{ref.name})"}
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

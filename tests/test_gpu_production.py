@@ -106,6 +106,25 @@ def test_pretrained_default_geometry_with_fused_adaln_matches_oracle(monkeypatch
     _compare(aurora_amd.AuroraPretrained, {}, 181, 360, LEVELS13)
 
 
+def test_attention_layouts_give_the_same_prediction_bit_for_bit(monkeypatch):
+    """q | k | v in head planes in front of the window attention (csrc/step.hip: m.qkv_planes) is a LAYOUT: the qkv linear and
+    the attention do the same arithmetic on the same values wherever they lie.  Both settings of the switch must reproduce the
+    same prediction exactly -- at the production widths, with the stage-0 proj / fc2 linears fused with their AdaLN and without.
+    (Round 5 ran the same test over a third switch -- the attention's RESULT in head planes, read by the proj linear -- before
+    that layout was measured and dropped: profiles/r05_ab_attention_out_planes.log.)"""
+    outs = {}
+    for qp, fuse in (("1", "2"), ("0", "2"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("AURORA_QKV_PLANES", qp)
+        monkeypatch.setenv("AURORA_FUSE_LN", fuse)
+        model = _seeded_model(aurora_amd.AuroraPretrained, autocast=True)
+        batch = _inputs(model.config, 181, 360, LEVELS13)
+        outs[(qp, fuse)] = _engine(model, batch)
+        del model
+        torch.cuda.empty_cache()
+    for fuse in ("2", "0"):
+        assert all(torch.equal(outs[("0", fuse)][k], v) for k, v in outs[("1", fuse)].items()), fuse
+
+
 def test_pretrained_quarter_grid_matches_oracle():
     """AuroraPretrained() on 361 x 720 = a quarter of the 0.25-degree tokens (token grid (4, 90, 180); stages (45, 90) and
     (23, 45) padded): M = 64,800 / 16,200 / 4,140 rows per stage, so the M-dependent dispatch of the headline step is
