@@ -321,6 +321,8 @@ def main() -> None:
             raise SystemExit(3)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    control = dist.new_group(backend="gloo") if distributed else None   # host-side agreement between ranks (see below)
+    bands_error = None
 
     mode = os.environ.get("AURORA_BENCH_MODE", "bands") if distributed else "single"
     assert mode in ("bands", "replicas", "single"), mode
@@ -336,13 +338,33 @@ def main() -> None:
         # before anything is timed: every rank sends a stamped pattern of a real halo message's size to its neighbours
         # through the production transport and checks what arrived (a wrong rank order / fabric / stream order fails here)
         transport = model.engine().native.transport
+        test_error = None
         try:
+            if os.environ.get("AURORA_BENCH_BREAK_SELFTEST") == str(rank):   # test hook: this rank's fabric "fails"
+                raise RuntimeError("self-test broken on purpose (AURORA_BENCH_BREAK_SELFTEST)")
             transport.selftest(4 << 20)
         except Exception as e:  # noqa: BLE001
-            print(json.dumps({"metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13", "value": None, "n_gpus": world,
-                              "rank": rank, "error": f"halo transport self-test failed: {e!r}"}), flush=True)
+            test_error = f"halo transport self-test failed on rank {rank}: {e!r}"
+        # every rank must take the same branch: agreement runs over a host-side (gloo) group, which works whatever state the
+        # failed point-to-point operation left RCCL in
+        errors = [None] * world
+        dist.all_gather_object(errors, test_error, group=control)
+        bands_error = next((e for e in errors if e), None)
+        if bands_error is None:
+            log("halo transport self-test ok")
+        elif os.environ.get("AURORA_BENCH_NO_FALLBACK"):
+            if rank == 0:
+                print(json.dumps({"metric": "forecast-steps/sec (6h step) 0.25deg ERA5 721x1440x13", "value": None,
+                                  "n_gpus": world, "error": bands_error}), flush=True)
             raise SystemExit(4)
-        log("halo transport self-test ok")
+        else:
+            # The sharded forecast cannot run on this fabric: rather than no record at all, every rank advances its OWN
+            # forecast (no data-path collective) and the line says so -- "scaling": "weak", `bands_error` carries the reason.
+            log(f"{bands_error} -- falling back to independent replicas")
+            mode = "replicas"
+            model.configure_sharding(0, 1)
+            del batch, transport
+            batch = synthetic_batch(model.config, GH, GW, 1 + rank, device)
     else:
         batch = synthetic_batch(model.config, GH, GW, 1 + (rank if mode == "replicas" else 0), device)
     log("batch on device")
@@ -477,6 +499,8 @@ def main() -> None:
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if bands_error is not None:   # asked for a sharded forecast, measured replicas: the record says why
+            out["bands_error"] = bands_error
         # the GPU measurement is safe in the log before the (long) CPU leg starts: a driver that gives up on the CPU oracle
         # still finds it on stderr; stdout carries exactly one line, at the end
         log("GPU-only result: " + json.dumps(out))

@@ -59,3 +59,13 @@ def test_bench_gpus_2_launches_its_own_ranks():
     pr = d["per_rank"]
     assert len(pr["step_ms"]) == len(pr["halo_wait_ms"]) == len(pr["compute_ms"]) == 2
     assert all(w >= 0 for w in pr["halo_wait_ms"]) and pr["max_rank_compute_ms"] == max(pr["compute_ms"]) > 0
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_replicas_when_the_halo_self_test_fails():
+    """A fabric on which the halo self-test fails on ANY rank: every rank learns of it (host-side agreement), the run measures
+    independent replicas instead of ending without a record, and the line says so."""
+    d = _run(["--gpus", "2", "--grid", "181x360", "--steps", "2", "--warmup", "1"],
+             env={"AURORA_BENCH_SAME_GPU": "1", "AURORA_BENCH_BACKEND": "gloo", "AURORA_BENCH_BREAK_SELFTEST": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "per_rank" not in d
+    assert "rank 1" in d["bands_error"] and "replica" in d["config"]["parallelism"]
