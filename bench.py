@@ -340,9 +340,11 @@ def main() -> None:
         transport = model.engine().native.transport
         test_error = None
         try:
-            if os.environ.get("AURORA_BENCH_BREAK_SELFTEST") == str(rank):   # test hook: this rank's fabric "fails"
-                raise RuntimeError("self-test broken on purpose (AURORA_BENCH_BREAK_SELFTEST)")
             transport.selftest(4 << 20)
+            # test hook: this rank's check "fails" -- AFTER it took part in the exchange, like a real verification failure
+            # (a rank that stayed away from the exchange would leave its neighbours waiting for a message, not failing)
+            if os.environ.get("AURORA_BENCH_BREAK_SELFTEST") == str(rank):
+                raise RuntimeError("self-test broken on purpose (AURORA_BENCH_BREAK_SELFTEST)")
         except Exception as e:  # noqa: BLE001
             test_error = f"halo transport self-test failed on rank {rank}: {e!r}"
         # every rank must take the same branch: agreement runs over a host-side (gloo) group, which works whatever state the
