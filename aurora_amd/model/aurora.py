@@ -218,7 +218,13 @@ class Aurora(nn.Module):
         # .to() / .double() / .cuda() that really change storage drop the packed weights; a no-op `.to(device)` on a model
         # that is already there (foundry's `Model.run` does one per request) keeps the handle, its weights and workspace
         # (buffers and in-place writes count too: `_version` moves when `fn` writes a tensor in place)
-        stamp = lambda: [(t.data_ptr(), t.dtype, t.device, t._version)  # noqa: E731
+        def version(t):
+            try:
+                return t._version
+            except RuntimeError:   # inference tensors (a model built under `torch.inference_mode()`) carry no counter
+                return -1
+
+        stamp = lambda: [(t.data_ptr(), t.dtype, t.device, version(t))  # noqa: E731
                          for t in (*self.parameters(), *self.buffers())]
         before = stamp()
         out = super()._apply(fn, *args, **kwargs)

@@ -51,3 +51,13 @@ def test_cpu_forward_fails_loudly():
     model = aurora_amd.AuroraSmallPretrained()
     with pytest.raises(RuntimeError, match="HIP device"):
         model.forward(None)
+
+
+def test_a_model_built_under_inference_mode_can_be_moved():
+    """`Aurora._apply` stamps parameters and buffers (data_ptr, dtype, device, version) to decide whether the packed weights
+    survive a `.to()`; inference tensors carry no version counter -- asking for one used to raise out of `.to()`."""
+    with torch.inference_mode():
+        model = aurora_amd.AuroraSmallPretrained()
+    assert model.to("cpu") is model
+    with torch.inference_mode():
+        assert model.double() is model and next(model.parameters()).dtype == torch.float64
