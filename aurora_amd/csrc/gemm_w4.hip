@@ -1,0 +1,409 @@
+// Four-wave form of the 256 x 256 bf16 GEMM tile: ONE wave per SIMD with the whole 512-register file, wave tile 128 x 128.
+//
+// Why (round 5): the ping-pong kernel (gemm.hip: eight waves, wave tile 128 x 64) was measured against the vendor library
+// for the first time (profiles/r05_vendor_gemm_yardstick.log) -- it wins on the K = 512 shapes and LOSES 9-17 % on every
+// K >= 1024 shape.  rocprofv3 names the vendor's kernel: MT256x256x64, MIWT8_8 (wave tile 128 x 128), 256 threads,
+// 16x16 MFMAs.  The arithmetic of the difference is LDS traffic: per 32-wide K-step a 128 x 64 wave tile reads
+// (128 + 64) x 64 B of fragments for 32 MFMAs, a 128 x 128 one (128 + 128) x 64 B for 64 -- 96 KiB against 64 KiB per
+// CU and K-step, next to the 32 KiB the LDS-DMA writes.  The ping-pong schedule needs its load phase (~600 cycles of LDS
+// reads) as long as its matrix phase (543); here the reads of stage s+1 sit in the shadow of the 64 MFMAs of stage s.
+//
+// Structure (per workgroup = per CU): the same 4-stage LDS ring, stage image, swizzles, tile order and epilogues as
+// gemm.hip's 256 x 256 kernels (this file includes that one for them) -- so results are bit-identical: every output
+// accumulates K in the same 32-wide steps.  Waves 2 (m) x 2 (n).  Registers: 256 accumulators (AGPRs), two fragment
+// sets of 16 x 4 registers (stage s being multiplied, stage s+1 arriving).  Iteration s:
+//     eight groups of { 2 fragment reads of stage s+1, 1 LDS-DMA piece of stage s+4 (into the slot of stage s),
+//                       8 MFMAs of stage s }, pinned by sched_barrier so that the reads and the DMA issue between MFMAs;
+//     s_waitcnt vmcnt(16)   this wave's pieces of stage s+2 have landed (s+3, s+4 stay in flight);
+//     s_waitcnt lgkmcnt(0)  its reads of stage s+1 are done;
+//     ONE s_barrier         RAW: stage s+2 is complete for everyone;  WAR: nobody reads stage s+1's slot any more.
+// One barrier per 64 MFMAs (the ping-pong form: two per 32).  The ring is refilled unconditionally (stages past the
+// end re-load the last one into a dead slot), so every iteration is the same code and the counted waits never change.
+#define AURORA_GEMM_W4_TU 1
+#include "gemm.hip"
+
+namespace aurora {
+
+namespace {
+
+constexpr int W4_THREADS = 256;
+
+// c += a . b^T on the matrix pipe with the accumulator tile IN PLACE in AGPRs.  As a builtin, hipcc allocates destination
+// and source accumulator separately at one wave per SIMD and shuffles tiles between AGPRs and VGPRs around every MFMA of
+// the loop (168 v_accvgpr moves per two K-steps); the tied "+a" operand leaves nothing to allocate.  The statements are
+// volatile: they issue in source order, which is the schedule.
+__device__ __forceinline__ void mma_acc(f32x4& c, u32x4 a, u32x4 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+// ABLATE (timing probes with WRONG results, never dispatched by the library's own rule): 1 no barrier in the loop, 2 no
+// fragment reads, 3 no LDS-DMA refill, 4 none of the three (MFMAs only)
+template <int NST, int ABLATE = 0>   // stages of the LDS ring: 4 (128 KiB, stages s+2 .. s+4 in flight) or 5 (160 KiB, s+2 .. s+5)
+__global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void linear_kernel_256w4(const LinearArgs p_in) {
+  const LinearArgs p = batch_problem(p_in);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn2 = wave & 1;
+  const uint32_t nb = (uint32_t)p.n_blocks;
+  uint32_t tile_m, tile_n;
+  tile_of_block(blockIdx.x, nb, nb / (uint32_t)p.tiles_n, (uint32_t)p.tiles_n, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM2;
+  const int n0 = (int)tile_n * BN2;
+  const int nt = p.k_tiles;
+
+  const char* src_x[4];
+  const char* src_w[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int id = r * W4_THREADS + tid;
+    const int row = id >> 2, c = id & 3;
+    int64_t gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + row;
+    gn = gn < p.N ? gn : p.N - 1;
+    src_x[r] = p.A + gm * p.lda_b + ((c ^ swz2_x(row)) << 4);
+    src_w[r] = p.W + (int64_t)gn * p.ldw_b + ((c ^ swz2_w(row)) << 4);
+  }
+  // piece j (0..7) of stage kt into ring slot `slot`: four activation pieces, then four weight pieces.  Past the end the last
+  // stage is loaded again (into a slot nobody reads): every iteration is the same code, the counted waits never change.
+  auto stage_piece_at = [&](int kt, int slot, int j) {
+    const int kc = kt < nt ? kt : nt - 1;
+    const int64_t koff = (int64_t)kc * ROW2;
+    char* base = smem + slot * STAGE2;
+    const int r = j & 3;
+    if (j < 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[r] + koff),
+                                       (lds_ptr_t)(base + (r * W4_THREADS + wave * 64) * 16), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[r] + koff),
+                                       (lds_ptr_t)(base + OPER2 + (r * W4_THREADS + wave * 64) * 16), 16, 0, 0);
+  };
+
+  // fragment addresses: the swizzle of a row does not depend on the fragment index, so the eight fragments of an operand
+  // are one base plus immediates
+  const int i16 = lane & 15, g = lane >> 4;
+  int off_x0, off_w0;
+  {
+    const int row = wm * 128 + i16;
+    off_x0 = row * ROW2 + ((g ^ swz2_x(row)) << 4);
+    const int roww = wn2 * 128 + 16 * (i16 >> 2) + (i16 & 3);
+    off_w0 = OPER2 + roww * ROW2 + ((g ^ swz2_w(roww)) << 4);
+  }
+  auto read_x = [&](const char* buf, int f) { return *reinterpret_cast<const u32x4*>(buf + off_x0 + f * 16 * ROW2); };
+  // weight fragment j = 4 h + fn: half h (64 columns) of the wave's 128, n-fragment fn (rows 4 fn + .. interleaved)
+  auto read_w = [&](const char* buf, int j) {
+    return *reinterpret_cast<const u32x4*>(buf + off_w0 + (j >> 2) * 64 * ROW2 + (j & 3) * 4 * ROW2);
+  };
+
+  f32x4 acc[2][4][8];   // [half][fn][fm]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ax[8], aw[8], bx[8], bw[8];
+  // One K-step: the 64 MFMAs of the fragments in (cx, cw), the 16 reads of the next stage (ring slot `rs`) into (nx, nw) and
+  // the 8 LDS-DMA pieces of stage `kt` into slot `ws` -- at most one of them between two MFMAs, each in the shadow of the 16
+  // cycles the matrix pipe needs for the MFMA before it (pinned by the sched_barriers: hipcc knows no latency of an asm
+  // statement and would put all loads of a group in front of its MFMAs).
+  auto step = [&](int rs, int kt, int ws, u32x4 (&cx)[8], u32x4 (&cw)[8], u32x4 (&nx)[8], u32x4 (&nw)[8]) {
+    const char* nbuf = smem + rs * STAGE2;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mma_acc(acc[0][0][q], cw[0], cx[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ABLATE != 2 && ABLATE != 4) nw[q] = read_w(nbuf, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[0][1][q], cw[1], cx[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ABLATE != 2 && ABLATE != 4) nx[q] = read_x(nbuf, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[0][2][q], cw[2], cx[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ABLATE != 3 && ABLATE != 4) stage_piece_at(kt, ws, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[0][3][q], cw[3], cx[q]);
+      mma_acc(acc[1][0][q], cw[4], cx[q]);
+      mma_acc(acc[1][1][q], cw[5], cx[q]);
+      mma_acc(acc[1][2][q], cw[6], cx[q]);
+      mma_acc(acc[1][3][q], cw[7], cx[q]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // own pieces of the stage after next have landed (NST - 2 younger stages stay in flight), the fragment reads are done --
+    // as ONE s_waitcnt the compiler can see (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14): behind an
+    // opaque asm wait hipcc's counter model still holds the reads pending and puts an lgkmcnt(0) in front of the next MFMA
+    if constexpr (ABLATE == 3 || ABLATE == 4) __builtin_amdgcn_s_waitcnt(0x0070);
+    else if constexpr (NST == 4) __builtin_amdgcn_s_waitcnt(0x4070);   // vmcnt(16) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x4078);                      // vmcnt(24) lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ABLATE != 1 && ABLATE != 4) __builtin_amdgcn_s_barrier();   // RAW: that stage is complete for everyone.  WAR: nobody reads slot `rs` any more.
+    asm volatile("" ::: "memory");
+  };
+#pragma unroll
+  for (int kt = 0; kt < NST; ++kt)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) stage_piece_at(kt, kt, j);
+  if constexpr (NST == 4) __builtin_amdgcn_s_waitcnt(0x4F78);   // vmcnt(24): own pieces of stage 0
+  else __builtin_amdgcn_s_waitcnt(0x8F70);                      // vmcnt(32)
+  __builtin_amdgcn_s_barrier();                                 // stage 0 is complete
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    aw[f] = read_w(smem, f);
+    ax[f] = read_x(smem, f);
+  }
+  if constexpr (NST == 4) __builtin_amdgcn_s_waitcnt(0x4070);   // own pieces of stage 1; the fragments of stage 0
+  else __builtin_amdgcn_s_waitcnt(0x4078);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();   // stage 1 is complete; nobody reads slot 0 any more
+  asm volatile("" ::: "memory");
+  if constexpr (ABLATE == 2 || ABLATE == 4) {   // (no reads: both fragment sets hold stage 0 for good)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bx[q] = ax[q]; bw[q] = aw[q]; }
+  }
+  // iteration s: registers hold stage s (slot r, free), reads take stage s+1 (slot r+1), the DMA puts stage s+NST into slot r
+  int s = 0, r = 0;
+  auto next = [](int v) { return v + 1 == NST ? 0 : v + 1; };
+  for (; s + 1 < nt; s += 2) {
+    const int r1 = next(r);
+    step(r1, s + NST, r, ax, aw, bx, bw);
+    r = next(r1);
+    step(r, s + 1 + NST, r1, bx, bw, ax, aw);
+  }
+  if (s < nt) step(next(r), s + NST, r, ax, aw, bx, bw);
+  __builtin_amdgcn_s_waitcnt(0x0070);   // the re-loads past the end have landed: the ring is dead
+  __builtin_amdgcn_s_barrier();
+  // (the MFMAs are opaque to hipcc's hazard recogniser: the last results must have left the matrix pipe before the
+  // epilogue's v_accvgpr_read -- 16 passes = 64 cycles at most)
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  // the epilogues of the eight-wave kernels, once per 64-column half: half h of wave (wm, wn2) is their wave (wm, 2 wn2 + h)
+  // (written out, not a loop over h: hipcc declines to unroll a loop around the two inlined epilogues, and a run-time index
+  // into the accumulators would put all 256 of them on the stack)
+  const bool whole_rows = p.C2 == nullptr && p.res == nullptr && p.vec_store;   // (uniform)
+  if (whole_rows) {
+    epilogue_256_bf16_coalesced<1>(p, acc[0], m0, n0, wm, 2 * wn2, wm * 4 + 2 * wn2, lane, smem);
+    epilogue_256_bf16_coalesced<1>(p, acc[1], m0, n0, wm, 2 * wn2 + 1, wm * 4 + 2 * wn2 + 1, lane, smem);
+  } else {
+    epilogue_256<bf16_t>(p, acc[0], m0, n0, wm, 2 * wn2, i16, g);
+    epilogue_256<bf16_t>(p, acc[1], m0, n0, wm, 2 * wn2 + 1, i16, g);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same tile with the operands staged THROUGH REGISTERS (global_load -> VGPR -> ds_write) instead of by LDS-DMA.
+// Why: the ablation of the kernel above (profiles/r05_ab_gemm_w4_ablation.log) -- without its barrier +1 %, without its
+// fragment reads +5 %, without its LDS-DMA refill +25 % (1,713 against 1,370 TFLOP/s at 8192^3; MFMAs alone 1,812).  A
+// wave that issues a global_load ... lds stands still for tens of cycles (round 4 measured the same thing from the other
+// side: the refill moved into the ping-pong kernel's matrix phase cost 5 %), and with one wave per SIMD nobody else feeds
+// the matrix pipe meanwhile.  A plain global_load returns into registers without holding the wave; the LDS write is a
+// ds_write_b128 two steps later.  Registers: 3 sets of 8 pieces (stages s+2, s+3, s+4), LDS: TWO slots.
+//   step s:  8 groups of { MFMA, read a weight fragment of stage s+1, MFMA, read an activation fragment, MFMA,
+//            global_load piece q of stage s+4, MFMA, ds_write piece q of stage s+2 (loaded two steps ago), 4 MFMAs };
+//            lgkmcnt(0); barrier  (RAW: stage s+2 is complete in its slot.  WAR: nobody reads stage s+1's slot any more,
+//            the next step's writes of stage s+3 go there).
+// The loop is unrolled six times (3 register sets x 2 fragment sets).
+template <int DUMMY>
+__global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void linear_kernel_256w4v(const LinearArgs p_in) {
+  const LinearArgs p = batch_problem(p_in);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn2 = wave & 1;
+  const uint32_t nb = (uint32_t)p.n_blocks;
+  uint32_t tile_m, tile_n;
+  tile_of_block(blockIdx.x, nb, nb / (uint32_t)p.tiles_n, (uint32_t)p.tiles_n, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM2;
+  const int n0 = (int)tile_n * BN2;
+  const int nt = p.k_tiles;
+
+  // piece r of an operand: row r * 64 + (tid >> 2), 16-byte piece (tid & 3) ^ swizzle.  Uniform tile base (scalar) + a
+  // 32-bit per-lane offset, so that the loads take the saddr form and an address costs one register
+  const char* const base_x = p.A + m0 * p.lda_b;
+  const char* const base_w = p.W + (int64_t)n0 * p.ldw_b;
+  uint32_t vo_x[4], vo_w[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r * 64 + (tid >> 2), c = tid & 3;
+    int64_t gm = m0 + row;
+    gm = (gm < p.M ? gm : p.M - 1) - m0;
+    int gn = n0 + row;
+    gn = (gn < p.N ? gn : p.N - 1) - n0;
+    vo_x[r] = (uint32_t)(gm * p.lda_b + ((c ^ swz2_x(row)) << 4));
+    vo_w[r] = (uint32_t)((int64_t)gn * p.ldw_b + ((c ^ swz2_w(row)) << 4));
+  }
+  // buffer loads: descriptor of the tile's rows (scalar) + per-lane offset (ONE register) + scalar K offset -- a global_load
+  // needs a 64-bit per-lane address per piece: 16 registers hipcc had to spill, and a scratch reload is a vmcnt(0)
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)base_x, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)base_w, 0, 0x7fffffff, 0x00020000);
+  auto load_piece = [&](int kt, int j) -> u32x4 {
+    const int kc = kt < nt ? kt : nt - 1;   // past the end: the last stage again (written to a slot nobody reads)
+    const int koff = kc * ROW2;
+    const int r = j & 3;
+    return j < 4 ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo_x[r], koff, 0)
+                 : __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)vo_w[r], koff, 0);
+  };
+  // LDS image of a stage: as the LDS-DMA kernels write it (piece id = r * 256 + tid at byte id * 16)
+  char* const wr0 = smem + tid * 16;
+  auto write_piece = [&](int slot, int j, u32x4 v) {
+    *reinterpret_cast<u32x4*>(wr0 + slot * STAGE2 + (j < 4 ? 0 : OPER2) + (j & 3) * (W4_THREADS * 16)) = v;
+  };
+
+  const int i16 = lane & 15, g = lane >> 4;
+  int off_x0, off_w0;
+  {
+    const int row = wm * 128 + i16;
+    off_x0 = row * ROW2 + ((g ^ swz2_x(row)) << 4);
+    const int roww = wn2 * 128 + 16 * (i16 >> 2) + (i16 & 3);
+    off_w0 = OPER2 + roww * ROW2 + ((g ^ swz2_w(roww)) << 4);
+  }
+  auto read_x = [&](const char* buf, int f) { return *reinterpret_cast<const u32x4*>(buf + off_x0 + f * 16 * ROW2); };
+  auto read_w = [&](const char* buf, int j) {
+    return *reinterpret_cast<const u32x4*>(buf + off_w0 + (j >> 2) * 64 * ROW2 + (j & 3) * 4 * ROW2);
+  };
+
+  f32x4 acc[2][4][8];   // [half][fn][fm]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) acc[h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragments: the eight WEIGHT fragments of a stage are live for the whole step (two sets); activation fragment q is used by
+  // group q only, so stage s+1's is read into its place behind that group's MFMAs (one set).  3 x 32 + 3 x 32 staged
+  // registers: 192 of the 256 a lane has besides its accumulators.
+  u32x4 xf[8], aw[8], bw[8];
+  u32x4 g0[8], g1[8], g2[8];          // staged pieces on their way from memory to LDS
+  // step s: (xf, cw) = stage s; reads stage s+1 from slot (s+1) & 1 into (xf, nw); loads stage s+4 into `gl`; writes `gw`
+  // (stage s+2) into slot s & 1
+  auto step = [&](int s, u32x4 (&cw)[8], u32x4 (&nw)[8], u32x4 (&gl)[8], u32x4 (&gw)[8]) {
+    const char* nbuf = smem + ((s + 1) & 1) * STAGE2;
+    const int wslot = s & 1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mma_acc(acc[0][0][q], cw[0], xf[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      nw[q] = read_w(nbuf, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[0][1][q], cw[1], xf[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      write_piece(wslot, q, gw[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[0][2][q], cw[2], xf[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      gl[q] = load_piece(s + 4, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[0][3][q], cw[3], xf[q]);
+      mma_acc(acc[1][0][q], cw[4], xf[q]);
+      mma_acc(acc[1][1][q], cw[5], xf[q]);
+      mma_acc(acc[1][2][q], cw[6], xf[q]);
+      mma_acc(acc[1][3][q], cw[7], xf[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      xf[q] = read_x(nbuf, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only: the fragment reads and this wave's ds_writes are done
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // prologue: stages 0, 1, 2 into the register sets; 0 and 1 into the two slots; stage 3 into the set stage 0 left
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g0[j] = load_piece(0, j);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g1[j] = load_piece(1, j);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g2[j] = load_piece(2, j);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) write_piece(0, j, g0[j]);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) write_piece(1, j, g1[j]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g0[j] = load_piece(3, j);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();   // stages 0 and 1 are complete in LDS
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    aw[f] = read_w(smem, f);
+    xf[f] = read_x(smem, f);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();   // nobody reads slot 0 any more: step 0 writes stage 2 there
+  asm volatile("" ::: "memory");
+  // register sets by step (mod 3): step s writes the set of stage s+2 and loads into the set stage s+1 left:
+  //   s % 3 == 0: write g2, load g1;   1: write g0, load g2;   2: write g1, load g0
+  int s = 0;
+  for (; s + 6 <= nt; s += 6) {
+    step(s, aw, bw, g1, g2);
+    step(s + 1, bw, aw, g2, g0);
+    step(s + 2, aw, bw, g0, g1);
+    step(s + 3, bw, aw, g1, g2);
+    step(s + 4, aw, bw, g2, g0);
+    step(s + 5, bw, aw, g0, g1);
+  }
+  if (s < nt) step(s, aw, bw, g1, g2);
+  if (s + 1 < nt) step(s + 1, bw, aw, g2, g0);
+  if (s + 2 < nt) step(s + 2, aw, bw, g0, g1);
+  if (s + 3 < nt) step(s + 3, bw, aw, g1, g2);
+  if (s + 4 < nt) step(s + 4, aw, bw, g2, g0);
+  __builtin_amdgcn_s_waitcnt(0x0070);   // loads past the end have landed (their registers are dead; nothing else waits)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  const bool whole_rows = p.C2 == nullptr && p.res == nullptr && p.vec_store;   // (uniform)
+  if (whole_rows) {
+    epilogue_256_bf16_coalesced<1>(p, acc[0], m0, n0, wm, 2 * wn2, wm * 4 + 2 * wn2, lane, smem);
+    epilogue_256_bf16_coalesced<1>(p, acc[1], m0, n0, wm, 2 * wn2 + 1, wm * 4 + 2 * wn2 + 1, lane, smem);
+  } else {
+    epilogue_256<bf16_t>(p, acc[0], m0, n0, wm, 2 * wn2, i16, g);
+    epilogue_256<bf16_t>(p, acc[1], m0, n0, wm, 2 * wn2 + 1, i16, g);
+  }
+}
+
+}  // namespace
+
+}  // namespace aurora
+
+// The launcher gemm.hip's dispatch calls (C linkage: LinearArgs lives in each translation unit's anonymous namespace;
+// both see the same definition, gemm.hip's).
+extern "C" __attribute__((visibility("hidden"))) int aurora_w4_launch(const void* linear_args, unsigned n_blocks, unsigned batch,
+                                                                     int stages, void* stream) {
+  using namespace aurora;
+  static bool attr_done_dev[64] = {false};
+  bool& attr_done = attr_done_dev[current_device() & 63];
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256w4v<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
+    attr_done = true;
+  }
+  const LinearArgs& p = *static_cast<const LinearArgs*>(linear_args);
+  const dim3 gr(n_blocks, batch), bl(W4_THREADS);
+  switch (stages) {
+    case 5: hipLaunchKernelGGL(linear_kernel_256w4<5>, gr, bl, 5 * STAGE2, as_stream(stream), p); break;
+    case 6: hipLaunchKernelGGL(linear_kernel_256w4v<0>, gr, bl, 4 * STAGE2, as_stream(stream), p); break;
+    case 14: hipLaunchKernelGGL((linear_kernel_256w4<4, 1>), gr, bl, 4 * STAGE2, as_stream(stream), p); break;
+    case 24: hipLaunchKernelGGL((linear_kernel_256w4<4, 2>), gr, bl, 4 * STAGE2, as_stream(stream), p); break;
+    case 34: hipLaunchKernelGGL((linear_kernel_256w4<4, 3>), gr, bl, 4 * STAGE2, as_stream(stream), p); break;
+    case 44: hipLaunchKernelGGL((linear_kernel_256w4<4, 4>), gr, bl, 4 * STAGE2, as_stream(stream), p); break;
+    default: hipLaunchKernelGGL(linear_kernel_256w4<4>, gr, bl, 4 * STAGE2, as_stream(stream), p);
+  }
+  return 0;
+}

@@ -38,7 +38,9 @@ if len(sys.argv) > 2:  # restrict to the named shapes
 PRE = os.environ.get("GEMM_BENCH_PRESPLIT", "")
 FLAGS = (lib.F32_W_SPLIT if "w" in PRE else 0) | (lib.F32_A_SPLIT if "a" in PRE else 0) | (lib.F32_C_SPLIT if "c" in PRE else 0)
 ACT = int(os.environ.get("GEMM_BENCH_ACT", "0"))   # 1 = GELU epilogue
-tot_ms = tot_fl = 0.0
+VENDOR = bool(os.environ.get("GEMM_BENCH_VENDOR"))   # also time torch's own linear (hipBLASLt / rocBLAS) as a yardstick
+torch.backends.cuda.matmul.allow_tf32 = False
+tot_ms = tot_fl = ven_ms = 0.0
 for name, M, N, K, wt in SHAPES:
     a = (torch.rand(M, K, device="cuda") * 2 - 1).to(dtype)
     if os.environ.get("GEMM_BENCH_ZERO"):   # power experiment: all-zero operands toggle no datapath bits
@@ -66,7 +68,26 @@ for name, M, N, K, wt in SHAPES:
     fl = 2.0 * M * N * K
     tot_ms += ms * wt
     tot_fl += fl * wt
-    print(f"{name:8s} M={M:6d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s", flush=True)
+    vendor = ""
+    if VENDOR and not FLAGS:
+        # YARDSTICK ONLY (never part of the product path): the same product through the vendor library torch dispatches to
+        # (hipBLASLt / rocBLAS), same operands, bias in the call, GELU as a second kernel where asked for; fp32 = true fp32
+        # (allow_tf32 off, which is torch's default), i.e. what the reference's fp32 encoder / decoder would run on this GPU.
+        act = torch.nn.functional.gelu if ACT == 1 else (lambda t: t)
+        for _ in range(2):
+            act(torch.nn.functional.linear(a, w, b.to(dtype)))
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            act(torch.nn.functional.linear(a, w, b.to(dtype)))
+        e1.record()
+        torch.cuda.synchronize()
+        vms = e0.elapsed_time(e1) / reps
+        ven_ms += vms * wt
+        vendor = f"   | vendor library via torch {vms:8.3f} ms  {fl / vms / 1e9:8.1f} TFLOP/s  (x{vms / ms:.2f} of ours)"
+    print(f"{name:8s} M={M:6d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s{vendor}", flush=True)
     del a, w, out
 if tot_ms:
     print(f"weighted backbone: {tot_ms:.1f} ms/step, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s")
+    if ven_ms:
+        print(f"vendor library, same weights: {ven_ms:.1f} ms/step, {tot_fl / ven_ms / 1e9:.1f} TFLOP/s")
