@@ -197,18 +197,21 @@ void linear_kernel_256w4(const LinearArgs p_in) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same tile with the operands staged THROUGH REGISTERS (global_load -> VGPR -> ds_write) instead of by LDS-DMA.
-// Why: the ablation of the kernel above (profiles/r05_ab_gemm_w4_ablation.log) -- without its barrier +1 %, without its
-// fragment reads +5 %, without its LDS-DMA refill +25 % (1,713 against 1,370 TFLOP/s at 8192^3; MFMAs alone 1,812).  A
-// wave that issues a global_load ... lds stands still for tens of cycles (round 4 measured the same thing from the other
-// side: the refill moved into the ping-pong kernel's matrix phase cost 5 %), and with one wave per SIMD nobody else feeds
-// the matrix pipe meanwhile.  A plain global_load returns into registers without holding the wave; the LDS write is a
-// ds_write_b128 two steps later.  Registers: 3 sets of 8 pieces (stages s+2, s+3, s+4), LDS: TWO slots.
-//   step s:  8 groups of { MFMA, read a weight fragment of stage s+1, MFMA, read an activation fragment, MFMA,
-//            global_load piece q of stage s+4, MFMA, ds_write piece q of stage s+2 (loaded two steps ago), 4 MFMAs };
-//            lgkmcnt(0); barrier  (RAW: stage s+2 is complete in its slot.  WAR: nobody reads stage s+1's slot any more,
-//            the next step's writes of stage s+3 go there).
-// The loop is unrolled six times (3 register sets x 2 fragment sets).
+// The same tile with the operands staged THROUGH REGISTERS (buffer_load -> VGPR -> ds_write) in WHOLE 128-BYTE LINES.
+// Why: (1) the ablation of the kernel above (profiles/r05_ab_gemm_w4.log) -- without its barrier +1 %, without its fragment
+// reads +5 %, without its refill +25 % (1,713 against 1,370 TFLOP/s at 8192^3; MFMAs alone 1,812): what the tile pays for is
+// getting its operands, not multiplying them.  (2) Every kernel of gemm.hip asks for an operand row in 64-byte pieces, one
+// K-stage (32 bf16) at a time: a 128-byte cache line is requested from L2 twice, half a microsecond apart (the CU's 16 KiB
+// L1 has seen 32 KiB in between).  The vendor's kernel stages K = 64 (MT256x256x64): whole lines, half the requests.  LDS-DMA
+// cannot do that here without halving the ring (a lane's 16 bytes land at lane * 16: whole-line rows make 64 KiB stages),
+// registers can: eight lanes load the eight pieces of a row's line and write them into the images of TWO K-stages.
+//   even step s: 64 MFMAs of stage s; fragment reads of stage s+1; ds_write of stages s+2 and s+3 (loaded two steps ago);
+//                buffer_load of stages s+4 and s+5 (16 pieces) into the other register set; lgkmcnt(0); barrier
+//   odd step:    64 MFMAs of stage s+1; fragment reads of stage s+2.  No barrier: what it reads was complete at the last one,
+//                and nothing is written.
+// One barrier per 128 MFMAs; LDS: the four 32 KiB stage images as before (read s+1, write s+2 and s+3, s dead); registers:
+// 2 x 64 staged + 96 fragment registers (the activation fragment of group q is re-read in place behind its MFMAs).
+// Rows past M read as zero through the buffer descriptor's range check (their results are never stored).  K % 64 == 0.
 template <int DUMMY>
 __global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void linear_kernel_256w4v(const LinearArgs p_in) {
@@ -223,38 +226,38 @@ void linear_kernel_256w4v(const LinearArgs p_in) {
   tile_of_block(blockIdx.x, nb, nb / (uint32_t)p.tiles_n, (uint32_t)p.tiles_n, tile_m, tile_n);
   const int64_t m0 = (int64_t)tile_m * BM2;
   const int n0 = (int)tile_n * BN2;
-  const int nt = p.k_tiles;
+  const int nt = p.k_tiles;          // 32-wide K-stages (even)
+  const int nu = nt >> 1;            // 64-wide units of loading
 
-  // piece r of an operand: row r * 64 + (tid >> 2), 16-byte piece (tid & 3) ^ swizzle.  Uniform tile base (scalar) + a
-  // 32-bit per-lane offset, so that the loads take the saddr form and an address costs one register
-  const char* const base_x = p.A + m0 * p.lda_b;
-  const char* const base_w = p.W + (int64_t)n0 * p.ldw_b;
-  uint32_t vo_x[4], vo_w[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = r * 64 + (tid >> 2), c = tid & 3;
-    int64_t gm = m0 + row;
-    gm = (gm < p.M ? gm : p.M - 1) - m0;
-    int gn = n0 + row;
-    gn = (gn < p.N ? gn : p.N - 1) - n0;
-    vo_x[r] = (uint32_t)(gm * p.lda_b + ((c ^ swz2_x(row)) << 4));
-    vo_w[r] = (uint32_t)((int64_t)gn * p.ldw_b + ((c ^ swz2_w(row)) << 4));
-  }
-  // buffer loads: descriptor of the tile's rows (scalar) + per-lane offset (ONE register) + scalar K offset -- a global_load
-  // needs a 64-bit per-lane address per piece: 16 registers hipcc had to spill, and a scratch reload is a vmcnt(0)
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)base_x, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)base_w, 0, 0x7fffffff, 0x00020000);
-  auto load_piece = [&](int kt, int j) -> u32x4 {
-    const int kc = kt < nt ? kt : nt - 1;   // past the end: the last stage again (written to a slot nobody reads)
-    const int koff = kc * ROW2;
-    const int r = j & 3;
-    return j < 4 ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo_x[r], koff, 0)
-                 : __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)vo_w[r], koff, 0);
+  // piece r (0..7) of an operand: row r * 32 + (tid >> 3), 16-byte piece c8 = tid & 7 of the row's 128-byte line
+  const int c8 = tid & 7, row0 = tid >> 3;
+  const int64_t rows_x = p.M - m0 < BM2 ? p.M - m0 : BM2;
+  const int64_t bytes_x = rows_x * p.lda_b, bytes_w = (int64_t)BN2 * p.ldw_b;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + m0 * p.lda_b), 0, (int)(bytes_x < 0x7fffffff ? bytes_x : 0x7fffffff), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.W + (int64_t)n0 * p.ldw_b), 0, (int)(bytes_w < 0x7fffffff ? bytes_w : 0x7fffffff), 0x00020000);
+  const int vo_x0 = (int)(row0 * p.lda_b) + c8 * 16, vo_w0 = (int)(row0 * p.ldw_b) + c8 * 16;
+  const int ld32_x = (int)(32 * p.lda_b), ld32_w = (int)(32 * p.ldw_b);   // (uniform)
+  // piece j of unit u: j < 8 activations (r = j), else weights.  The row part goes into the per-lane offset (one add), so
+  // that the descriptor's range check sees it; the K part is the scalar offset.
+  auto load_piece = [&](int u, int j) -> u32x4 {
+    const int uc = u < nu ? u : nu - 1;   // past the end: the last unit again (written to stage images nobody reads)
+    const int koff = uc * 128;
+    const int r = j & 7;
+    return j < 8 ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo_x0 + r * ld32_x, koff, 0)
+                 : __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_w0 + r * ld32_w, koff, 0);
   };
-  // LDS image of a stage: as the LDS-DMA kernels write it (piece id = r * 256 + tid at byte id * 16)
-  char* const wr0 = smem + tid * 16;
-  auto write_piece = [&](int slot, int j, u32x4 v) {
-    *reinterpret_cast<u32x4*>(wr0 + slot * STAGE2 + (j < 4 ? 0 : OPER2) + (j & 3) * (W4_THREADS * 16)) = v;
+  // where a piece goes: stage image (c8 >> 2) of the unit's two, row, position (c8 & 3) ^ swizzle -- the image the LDS-DMA
+  // kernels write (gemm.hip).  The activation swizzle does not depend on r; the weight one does through r & 1.
+  const int half_off = (c8 >> 2) * STAGE2;
+  char* const wr_x = smem + half_off + row0 * ROW2 + (((c8 & 3) ^ swz2_x(row0)) << 4);
+  char* const wr_w0 = smem + half_off + OPER2 + row0 * ROW2 + (((c8 & 3) ^ swz2_w(row0)) << 4);
+  char* const wr_w1 = smem + half_off + OPER2 + (row0 + 32) * ROW2 + (((c8 & 3) ^ swz2_w(row0 + 32)) << 4);
+  auto write_piece = [&](int unit_slot, int j, u32x4 v) {   // unit_slot: 0 / 1 = stage images {0, 1} / {2, 3}
+    const int r = j & 7;
+    char* dst = j < 8 ? wr_x + r * 32 * ROW2 : ((r & 1) ? wr_w1 + (r >> 1) * 64 * ROW2 : wr_w0 + (r >> 1) * 64 * ROW2);
+    *reinterpret_cast<u32x4*>(dst + unit_slot * 2 * STAGE2) = v;
   };
 
   const int i16 = lane & 15, g = lane >> 4;
@@ -278,16 +281,12 @@ void linear_kernel_256w4v(const LinearArgs p_in) {
 #pragma unroll
       for (int b = 0; b < 8; ++b) acc[h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragments: the eight WEIGHT fragments of a stage are live for the whole step (two sets); activation fragment q is used by
-  // group q only, so stage s+1's is read into its place behind that group's MFMAs (one set).  3 x 32 + 3 x 32 staged
-  // registers: 192 of the 256 a lane has besides its accumulators.
-  u32x4 xf[8], aw[8], bw[8];
-  u32x4 g0[8], g1[8], g2[8];          // staged pieces on their way from memory to LDS
-  // step s: (xf, cw) = stage s; reads stage s+1 from slot (s+1) & 1 into (xf, nw); loads stage s+4 into `gl`; writes `gw`
-  // (stage s+2) into slot s & 1
-  auto step = [&](int s, u32x4 (&cw)[8], u32x4 (&nw)[8], u32x4 (&gl)[8], u32x4 (&gw)[8]) {
-    const char* nbuf = smem + ((s + 1) & 1) * STAGE2;
-    const int wslot = s & 1;
+  u32x4 xf[8], aw[8], bw[8];   // fragments: one activation set (re-read in place), two weight sets
+  u32x4 ga[16], gb[16];        // two units on their way from memory to LDS
+  // even step s (unit s / 2): writes `gw` = unit s/2 + 1 into the stage images of s+2, s+3; loads unit s/2 + 2 into `gl`
+  auto even_step = [&](int s, u32x4 (&cw)[8], u32x4 (&nw)[8], u32x4 (&gl)[16], u32x4 (&gw)[16]) {
+    const char* nbuf = smem + ((s + 1) & 3) * STAGE2;
+    const int wslot = ((s + 2) >> 1) & 1, u = (s >> 1) + 2;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       mma_acc(acc[0][0][q], cw[0], xf[q]);
@@ -296,12 +295,42 @@ void linear_kernel_256w4v(const LinearArgs p_in) {
       __builtin_amdgcn_sched_barrier(0);
       mma_acc(acc[0][1][q], cw[1], xf[q]);
       __builtin_amdgcn_sched_barrier(0);
-      write_piece(wslot, q, gw[q]);
+      write_piece(wslot, 2 * q, gw[2 * q]);
       __builtin_amdgcn_sched_barrier(0);
       mma_acc(acc[0][2][q], cw[2], xf[q]);
       __builtin_amdgcn_sched_barrier(0);
-      gl[q] = load_piece(s + 4, q);
+      write_piece(wslot, 2 * q + 1, gw[2 * q + 1]);
       __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[0][3][q], cw[3], xf[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      gl[2 * q] = load_piece(u, 2 * q);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[1][0][q], cw[4], xf[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      gl[2 * q + 1] = load_piece(u, 2 * q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[1][1][q], cw[5], xf[q]);
+      mma_acc(acc[1][2][q], cw[6], xf[q]);
+      mma_acc(acc[1][3][q], cw[7], xf[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      xf[q] = read_x(nbuf, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the fragment reads and this wave's ds_writes are done
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();   // RAW: stages s+2, s+3 are complete.  WAR: the images of s, s+1 may be written from s+2 on.
+    asm volatile("" ::: "memory");
+  };
+  auto odd_step = [&](int s, u32x4 (&cw)[8], u32x4 (&nw)[8]) {
+    const char* nbuf = smem + ((s + 1) & 3) * STAGE2;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mma_acc(acc[0][0][q], cw[0], xf[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      nw[q] = read_w(nbuf, q);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_acc(acc[0][1][q], cw[1], xf[q]);
+      mma_acc(acc[0][2][q], cw[2], xf[q]);
       mma_acc(acc[0][3][q], cw[3], xf[q]);
       mma_acc(acc[1][0][q], cw[4], xf[q]);
       mma_acc(acc[1][1][q], cw[5], xf[q]);
@@ -311,25 +340,14 @@ void linear_kernel_256w4v(const LinearArgs p_in) {
       xf[q] = read_x(nbuf, q);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only: the fragment reads and this wave's ds_writes are done
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
   };
-  // prologue: stages 0, 1, 2 into the register sets; 0 and 1 into the two slots; stage 3 into the set stage 0 left
+  // prologue: units 0 and 1 into the register sets, unit 0 into stage images 0, 1
 #pragma unroll
-  for (int j = 0; j < 8; ++j) g0[j] = load_piece(0, j);
+  for (int j = 0; j < 16; ++j) gb[j] = load_piece(0, j);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) g1[j] = load_piece(1, j);
+  for (int j = 0; j < 16; ++j) ga[j] = load_piece(1, j);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) g2[j] = load_piece(2, j);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) write_piece(0, j, g0[j]);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) write_piece(1, j, g1[j]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) g0[j] = load_piece(3, j);
+  for (int j = 0; j < 16; ++j) write_piece(0, j, gb[j]);
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();   // stages 0 and 1 are complete in LDS
@@ -339,27 +357,18 @@ void linear_kernel_256w4v(const LinearArgs p_in) {
     aw[f] = read_w(smem, f);
     xf[f] = read_x(smem, f);
   }
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_barrier();   // nobody reads slot 0 any more: step 0 writes stage 2 there
-  asm volatile("" ::: "memory");
-  // register sets by step (mod 3): step s writes the set of stage s+2 and loads into the set stage s+1 left:
-  //   s % 3 == 0: write g2, load g1;   1: write g0, load g2;   2: write g1, load g0
   int s = 0;
-  for (; s + 6 <= nt; s += 6) {
-    step(s, aw, bw, g1, g2);
-    step(s + 1, bw, aw, g2, g0);
-    step(s + 2, aw, bw, g0, g1);
-    step(s + 3, bw, aw, g1, g2);
-    step(s + 4, aw, bw, g2, g0);
-    step(s + 5, bw, aw, g0, g1);
+  for (; s + 4 <= nt; s += 4) {
+    even_step(s, aw, bw, gb, ga);       // writes unit s/2+1 (in ga), loads unit s/2+2 into gb
+    odd_step(s + 1, bw, aw);
+    even_step(s + 2, aw, bw, ga, gb);
+    odd_step(s + 3, bw, aw);
   }
-  if (s < nt) step(s, aw, bw, g1, g2);
-  if (s + 1 < nt) step(s + 1, bw, aw, g2, g0);
-  if (s + 2 < nt) step(s + 2, aw, bw, g0, g1);
-  if (s + 3 < nt) step(s + 3, bw, aw, g1, g2);
-  if (s + 4 < nt) step(s + 4, aw, bw, g2, g0);
-  __builtin_amdgcn_s_waitcnt(0x0070);   // loads past the end have landed (their registers are dead; nothing else waits)
+  if (s < nt) {
+    even_step(s, aw, bw, gb, ga);
+    odd_step(s + 1, bw, aw);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);   // loads past the end have landed (their registers are dead), the last reads are done
   __builtin_amdgcn_s_barrier();
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
@@ -398,7 +407,10 @@ extern "C" __attribute__((visibility("hidden"))) int aurora_w4_launch(const void
   const dim3 gr(n_blocks, batch), bl(W4_THREADS);
   switch (stages) {
     case 5: hipLaunchKernelGGL(linear_kernel_256w4<5>, gr, bl, 5 * STAGE2, as_stream(stream), p); break;
-    case 6: hipLaunchKernelGGL(linear_kernel_256w4v<0>, gr, bl, 4 * STAGE2, as_stream(stream), p); break;
+    case 6:   // whole-line register staging: K in units of 64
+      if (p.k_tiles % 2 == 0) hipLaunchKernelGGL(linear_kernel_256w4v<0>, gr, bl, 4 * STAGE2, as_stream(stream), p);
+      else hipLaunchKernelGGL(linear_kernel_256w4<4>, gr, bl, 4 * STAGE2, as_stream(stream), p);
+      break;
     case 14: hipLaunchKernelGGL((linear_kernel_256w4<4, 1>), gr, bl, 4 * STAGE2, as_stream(stream), p); break;
     case 24: hipLaunchKernelGGL((linear_kernel_256w4<4, 2>), gr, bl, 4 * STAGE2, as_stream(stream), p); break;
     case 34: hipLaunchKernelGGL((linear_kernel_256w4<4, 3>), gr, bl, 4 * STAGE2, as_stream(stream), p); break;
