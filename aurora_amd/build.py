@@ -16,10 +16,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "_lib" / "libaurora_hip.so"
-SOURCES = ("runtime.hip", "gemm.hip", "gemm_w4.hip", "attention.hip", "norm.hip", "embed.hip", "band.hip", "model.hip", "step.hip")
-# gemm_w4.hip holds 256 accumulators per lane in AGPRs (one wave per SIMD, 512 registers): it is the one file compiled
-# WITHOUT -amdgpu-mfma-vgpr-form=1 (it includes gemm.hip for the device-side helpers, hence the dependency below)
-NO_VGPR_FORM = ("gemm_w4.hip",)
+SOURCES = ("runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "embed.hip", "band.hip", "model.hip", "step.hip")
 ARCH = "gfx950"
 
 
@@ -49,8 +46,8 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
         obj = LIB.parent / (src.replace(".hip", ".o"))
         # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950 has one unified file);
         # otherwise the softmax in the attention kernel pays a v_accvgpr_read per score.
-        form = [] if src in NO_VGPR_FORM else ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *form, "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm",
+               "-amdgpu-mfma-vgpr-form=1", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -1705,13 +1705,6 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
 
 }  // namespace aurora
 
-// gemm_w4.hip includes this file for the device side above (LinearArgs, the ring's layout, tile order, epilogues); the host
-// side below belongs to this translation unit only.
-#ifndef AURORA_GEMM_W4_TU
-// gemm_w4.hip: the four-wave 256 x 256 tile (wave tile 128 x 128, one wave per SIMD) -- its own translation unit because it
-// must be compiled WITHOUT -amdgpu-mfma-vgpr-form (256 accumulators live in AGPRs there)
-extern "C" int aurora_w4_launch(const void* linear_args, unsigned n_blocks, unsigned batch, int stages, void* stream);
-
 using namespace aurora;
 
 namespace {
@@ -1727,21 +1720,6 @@ int default_f32_mode() {
 }  // namespace
 
 extern "C" int aurora_hip_default_f32_gemm(void) { return default_f32_mode(); }
-
-namespace {
-// Which plain bf16 linears on 256 x 256 tiles take the four-wave kernel: K >= AURORA_GEMM_W4_MIN_K (read once; 0 = never).
-bool use_w4(int K) {
-  static const int min_k = [] {
-    const char* e = getenv("AURORA_GEMM_W4_MIN_K");
-    return e ? atoi(e) : 0;
-  }();
-  return min_k > 0 && K >= min_k;
-}
-int w4_stages() {   // AURORA_GEMM_W4_STAGES=4|5: depth of the four-wave kernel's LDS ring
-  static const int v = [] { const char* e = getenv("AURORA_GEMM_W4_STAGES"); return e ? atoi(e) : 5; }();
-  return v;
-}
-}  // namespace
 
 namespace {
 // Scratch of a split-K launch, owned by the caller: fp32 slabs (split x 256 KiB per tile; contents do not matter) and one
@@ -1979,8 +1957,6 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (ksplit > 1)       // ping-pong main loop, one workgroup per K-slice of a tile
       hipLaunchKernelGGL(linear_kernel_256pp<true>, dim3((unsigned)(p.n_blocks * ksplit)), dim3(THREADS2), PP_LDS, as_stream(stream), p);
-    else if (p.k_tiles >= 4 && use_w4(K))   // one wave per SIMD, wave tile 128 x 128 (gemm_w4.hip)
-      aurora_w4_launch(&p, (unsigned)p.n_blocks, (unsigned)batch, w4_stages(), stream);
     else if (p.k_tiles >= 4)   // ping-pong main loop, one workgroup per tile
       hipLaunchKernelGGL(linear_kernel_256pp<false>, grid, dim3(THREADS2), PP_LDS, as_stream(stream), p);
     else
@@ -2040,4 +2016,3 @@ extern "C" int aurora_hip_linear_layernorm(const void* A, int64_t lda, const voi
   }
   return check_launch("linear_layernorm");
 }
-#endif  // AURORA_GEMM_W4_TU

@@ -11,9 +11,7 @@ for f in runtime attention norm embed band model step; do
   fi
 done
 $CC "$@" -c aurora_amd/csrc/gemm.hip -o $D/gemm.o
-# (the four-wave GEMM: its own flags -- no -amdgpu-mfma-vgpr-form --, and it includes gemm.hip)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c aurora_amd/csrc/gemm_w4.hip -o $D/gemm_w4.o
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC aurora_amd/_lib/var_cache/*.o $D/gemm.o $D/gemm_w4.o -o aurora_amd/_lib/libaurora_hip_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC aurora_amd/_lib/var_cache/*.o $D/gemm.o -o aurora_amd/_lib/libaurora_hip_$NAME.so
 rm -rf $D
 echo built aurora_amd/_lib/libaurora_hip_$NAME.so

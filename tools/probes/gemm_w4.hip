@@ -1,3 +1,9 @@
+// REFERENCE COPY of a round-5 experiment -- NOT built into libaurora_hip.so.  It was part of the library at commits dada72d and
+// ad67596 (aurora_amd/csrc/gemm_w4.hip, dispatched from gemm.hip's linear_impl behind AURORA_GEMM_W4_MIN_K / AURORA_GEMM_W4_STAGES;
+// build.py compiled it WITHOUT -amdgpu-mfma-vgpr-form=1; gemm.hip carried an `#ifndef AURORA_GEMM_W4_TU` guard around its host
+// side for the #include below): check those commits out to run it.  Every variant passed tests/test_gpu_ops.py -k "linear_bf16 or
+// planes"; none beat the eight-wave ping-pong kernel by more than 3 % (K >= 4096 only) -- profiles/r05_ab_gemm_w4.log, DESIGN.md 10.
+//
 // Four-wave form of the 256 x 256 bf16 GEMM tile: ONE wave per SIMD with the whole 512-register file, wave tile 128 x 128.
 //
 // Why (round 5): the ping-pong kernel (gemm.hip: eight waves, wave tile 128 x 64) was measured against the vendor library
