@@ -1,7 +1,7 @@
 // REFERENCE COPY of a round-5 experiment -- NOT built into libaurora_hip.so.  It was part of the library at commits dada72d and
 // ad67596 (aurora_amd/csrc/gemm_w4.hip, dispatched from gemm.hip's linear_impl behind AURORA_GEMM_W4_MIN_K / AURORA_GEMM_W4_STAGES;
 // build.py compiled it WITHOUT -amdgpu-mfma-vgpr-form=1; gemm.hip carried an `#ifndef AURORA_GEMM_W4_TU` guard around its host
-// side for the #include below): check those commits out to run it.  Every variant passed tests/test_gpu_ops.py -k "linear_bf16 or
+// side for the #include below): check those commits out to run it (the register-staged kernel below is one step further: inline-asm loads, form (7) of the log).  Every variant passed tests/test_gpu_ops.py -k "linear_bf16 or
 // planes"; none beat the eight-wave ping-pong kernel by more than 3 % (K >= 4096 only) -- profiles/r05_ab_gemm_w4.log, DESIGN.md 10.
 //
 // Four-wave form of the 256 x 256 bf16 GEMM tile: ONE wave per SIMD with the whole 512-register file, wave tile 128 x 128.
@@ -239,20 +239,34 @@ void linear_kernel_256w4v(const LinearArgs p_in) {
   const int c8 = tid & 7, row0 = tid >> 3;
   const int64_t rows_x = p.M - m0 < BM2 ? p.M - m0 : BM2;
   const int64_t bytes_x = rows_x * p.lda_b, bytes_w = (int64_t)BN2 * p.ldw_b;
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.A + m0 * p.lda_b), 0, (int)(bytes_x < 0x7fffffff ? bytes_x : 0x7fffffff), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.W + (int64_t)n0 * p.ldw_b), 0, (int)(bytes_w < 0x7fffffff ? bytes_w : 0x7fffffff), 0x00020000);
+  // buffer descriptors by hand (base, stride 0, bytes, gfx9 raw-buffer flags), uniform: the loads below are inline asm
+  auto descriptor = [](const char* base, int64_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    return u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b),
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu)),
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(bytes < 0x7fffffff ? bytes : 0x7fffffff)), 0x00020000u};
+  };
+  const u32x4 rs_x = descriptor(p.A + m0 * p.lda_b, bytes_x), rs_w = descriptor(p.W + (int64_t)n0 * p.ldw_b, bytes_w);
   const int vo_x0 = (int)(row0 * p.lda_b) + c8 * 16, vo_w0 = (int)(row0 * p.ldw_b) + c8 * 16;
   const int ld32_x = (int)(32 * p.lda_b), ld32_w = (int)(32 * p.ldw_b);   // (uniform)
   // piece j of unit u: j < 8 activations (r = j), else weights.  The row part goes into the per-lane offset (one add), so
   // that the descriptor's range check sees it; the K part is the scalar offset.
+  // INLINE ASM on purpose: hipcc puts an s_waitcnt vmcnt(n) in front of EVERY ds_write that stores a loaded register (16 per
+  // step, ~2 issue cycles per MFMA: profiles/r05_pmc_w4_forms.txt -- 19.6 cycles per MFMA where the vendor's wave needs
+  // 16.4).  It cannot see these loads; the step waits ONCE, by hand, in front of its first write.
   auto load_piece = [&](int u, int j) -> u32x4 {
     const int uc = u < nu ? u : nu - 1;   // past the end: the last unit again (written to stage images nobody reads)
     const int koff = uc * 128;
     const int r = j & 7;
-    return j < 8 ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo_x0 + r * ld32_x, koff, 0)
-                 : __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_w0 + r * ld32_w, koff, 0);
+    u32x4 v;
+    if (j < 8) {
+      const int vo = vo_x0 + r * ld32_x;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(vo), "s"(rs_x), "s"(koff) : "memory");
+    } else {
+      const int vo = vo_w0 + r * ld32_w;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(vo), "s"(rs_w), "s"(koff) : "memory");
+    }
+    return v;
   };
   // where a piece goes: stage image (c8 >> 2) of the unit's two, row, position (c8 & 3) ^ swizzle -- the image the LDS-DMA
   // kernels write (gemm.hip).  The activation swizzle does not depend on r; the weight one does through r & 1.
@@ -301,6 +315,7 @@ void linear_kernel_256w4v(const LinearArgs p_in) {
       __builtin_amdgcn_sched_barrier(0);
       mma_acc(acc[0][1][q], cw[1], xf[q]);
       __builtin_amdgcn_sched_barrier(0);
+      if (q == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the unit loaded two steps ago (nothing younger is in flight)
       write_piece(wslot, 2 * q, gw[2 * q]);
       __builtin_amdgcn_sched_barrier(0);
       mma_acc(acc[0][2][q], cw[2], xf[q]);
@@ -352,6 +367,8 @@ void linear_kernel_256w4v(const LinearArgs p_in) {
   for (int j = 0; j < 16; ++j) gb[j] = load_piece(0, j);
 #pragma unroll
   for (int j = 0; j < 16; ++j) ga[j] = load_piece(1, j);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // (both units: the counter is in order)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < 16; ++j) write_piece(0, j, gb[j]);
   __builtin_amdgcn_s_waitcnt(0xC07F);
