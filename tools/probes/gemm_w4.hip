@@ -1,7 +1,7 @@
 // REFERENCE COPY of a round-5 experiment -- NOT built into libaurora_hip.so.  It was part of the library at commits dada72d and
 // ad67596 (aurora_amd/csrc/gemm_w4.hip, dispatched from gemm.hip's linear_impl behind AURORA_GEMM_W4_MIN_K / AURORA_GEMM_W4_STAGES;
 // build.py compiled it WITHOUT -amdgpu-mfma-vgpr-form=1; gemm.hip carried an `#ifndef AURORA_GEMM_W4_TU` guard around its host
-// side for the #include below): check those commits out to run it (the register-staged kernel below is one step further: inline-asm loads, form (7) of the log).  Every variant passed tests/test_gpu_ops.py -k "linear_bf16 or
+// side for the #include below): check those commits out to run it (the register-staged kernel below is one step further: inline-asm loads, forms (7) and (8) of the log: the last kernel of this file runs on 32x32x16 MFMAs.  Every variant passed tests/test_gpu_ops.py -k "linear_bf16 or
 // planes"; none beat the eight-wave ping-pong kernel by more than 3 % (K >= 4096 only) -- profiles/r05_ab_gemm_w4.log, DESIGN.md 10.
 //
 // Four-wave form of the 256 x 256 bf16 GEMM tile: ONE wave per SIMD with the whole 512-register file, wave tile 128 x 128.
@@ -405,6 +405,259 @@ void linear_kernel_256w4v(const LinearArgs p_in) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The register-staged four-wave tile on v_mfma_f32_32x32x16_bf16.
+// Why: the counters of the forms above (profiles/r05_pmc_w4_forms.txt) -- a lone wave per SIMD spends 19.6 cycles per 16-cycle
+// MFMA where the vendor's spends 16.4: every LDS / VMEM instruction between two MFMAs costs issue cycles that a 16-cycle
+// matrix instruction does not cover.  A 32x32x16 MFMA occupies the pipe for 32 cycles: the same 48 memory instructions per
+// K-step fall between 32 MFMAs instead of 64, 1.5 per gap where the guide counts five as free.
+// Fragments (gfx950): A / B operand lane l = row / column l & 31, k = 8 (l >> 5) .. + 7; D register 4 a + b of lane l = row
+// 8 a + 4 (l >> 5) + b, column l & 31.  The MFMA's A operand is the WEIGHT tile again (D = C^T).  Weight row of operand row i
+// in 32-column block t of a 64-column half: 16 (2 t + ((i >> 2) & 1)) + 4 (i >> 3) + (i & 3) -- then register a, component b of
+// lane (c, h2) holds feature 16 (2 t + h2) + 4 a + b of token c: what lane (i16 = c & 15, g = 2 t + h2) of the eight-wave
+// kernels holds in acc[fn = a][fm = 2 tm + (c >> 4)].  Two swaps per register pair (v_permlane32_swap, then
+// v_permlane16_swap, on the blocks t = 0 / 1) put it there, and the eight-wave epilogues run unchanged.
+// LDS image of a stage: rows of 64 bytes as before, piece c of row r at position c ^ f((r >> 2) & 7), f(x) = (x & 3) ^ 3 (x >> 2):
+// the 16 lanes of a ds_read_b128 cycle (rows {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} of a fragment, one piece) then hit 16
+// distinct 16-byte slots -- for the activation rows and for the interleaved weight rows alike.
+// NOT bit-identical to the 16x16x32 kernels (K is summed in 16-wide steps and in the 32x32 instruction's internal order).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2_sw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mma32_acc(f32x16& c, u32x4 a, u32x4 b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ int swz8(int row) {
+  const int x = (row >> 2) & 7;
+  return (x & 3) ^ ((x >> 2) * 3);
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(W4_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void linear_kernel_256w4m(const LinearArgs p_in) {
+  const LinearArgs p = batch_problem(p_in);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn2 = wave & 1;
+  const uint32_t nb = (uint32_t)p.n_blocks;
+  uint32_t tile_m, tile_n;
+  tile_of_block(blockIdx.x, nb, nb / (uint32_t)p.tiles_n, (uint32_t)p.tiles_n, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * BM2;
+  const int n0 = (int)tile_n * BN2;
+  const int nt = p.k_tiles;          // 32-wide K-stages (even)
+  const int nu = nt >> 1;            // 64-wide units of loading
+
+  // ---- staging: as linear_kernel_256w4v (whole 128-byte lines through registers), with the image's swizzle swz8 ----
+  const int c8 = tid & 7, row0 = tid >> 3;
+  const int64_t rows_x = p.M - m0 < BM2 ? p.M - m0 : BM2;
+  const int64_t bytes_x = rows_x * p.lda_b, bytes_w = (int64_t)BN2 * p.ldw_b;
+  auto descriptor = [](const char* base, int64_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    return u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b),
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu)),
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(bytes < 0x7fffffff ? bytes : 0x7fffffff)), 0x00020000u};
+  };
+  const u32x4 rs_x = descriptor(p.A + m0 * p.lda_b, bytes_x), rs_w = descriptor(p.W + (int64_t)n0 * p.ldw_b, bytes_w);
+  const int vo_x0 = (int)(row0 * p.lda_b) + c8 * 16, vo_w0 = (int)(row0 * p.ldw_b) + c8 * 16;
+  const int ld32_x = (int)(32 * p.lda_b), ld32_w = (int)(32 * p.ldw_b);   // (uniform)
+  auto load_piece = [&](int u, int j) -> u32x4 {
+    const int uc = u < nu ? u : nu - 1;
+    const int koff = uc * 128;
+    const int r = j & 7;
+    u32x4 v;
+    if (j < 8) {
+      const int vo = vo_x0 + r * ld32_x;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(vo), "s"(rs_x), "s"(koff) : "memory");
+    } else {
+      const int vo = vo_w0 + r * ld32_w;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(vo), "s"(rs_w), "s"(koff) : "memory");
+    }
+    return v;
+  };
+  // rows r * 32 + row0: (row >> 2) & 7 = (row0 >> 2) & 7 whatever r, for both operands -- one write address each
+  char* const wr_x = smem + (c8 >> 2) * STAGE2 + row0 * ROW2 + (((c8 & 3) ^ swz8(row0)) << 4);
+  char* const wr_w = wr_x + OPER2;
+  auto write_piece = [&](int unit_slot, int j, u32x4 v) {   // unit_slot: 0 / 1 = stage images {0, 1} / {2, 3}
+    char* dst = (j < 8 ? wr_x : wr_w) + (j & 7) * 32 * ROW2;
+    *reinterpret_cast<u32x4*>(dst + unit_slot * 2 * STAGE2) = v;
+  };
+
+  // ---- fragments ----
+  const int c32 = lane & 31, h2 = lane >> 5;
+  int off_x0, off_w0[2];
+  {
+    const int row = wm * 128 + c32;                       // + 32 tm
+    off_x0 = row * ROW2;
+    // weight operand row i = c32 of block t (t = 0, 1 within a 64-column half; + 64 per half)
+    const int wrow = wn2 * 128 + 16 * ((c32 >> 2) & 1) + 4 * (c32 >> 3) + (c32 & 3);   // + 32 t + 64 h
+    off_w0[0] = OPER2 + wrow * ROW2;
+    off_w0[1] = wrow;   // (row number, for the swizzle)
+  }
+  const int sx = swz8(wm * 128 + c32);                   // (+ 32 tm does not change (row >> 2) & 7)
+  const int sw = swz8(off_w0[1]);                        // (+ 32 t + 64 h neither)
+  // piece 2 kh + h2 of the row, kh = 0 / 1: position (2 kh + h2) ^ swizzle
+  const int px0 = ((h2 ^ sx) << 4), px1 = (((2 + h2) ^ sx) << 4);
+  const int pw0 = ((h2 ^ sw) << 4), pw1 = (((2 + h2) ^ sw) << 4);
+  auto read_x = [&](const char* buf, int tm, int kh) {
+    return *reinterpret_cast<const u32x4*>(buf + off_x0 + tm * 32 * ROW2 + (kh ? px1 : px0));
+  };
+  auto read_w = [&](const char* buf, int tn, int kh) {   // tn = 0 .. 3: block t = tn & 1 of half tn >> 1
+    return *reinterpret_cast<const u32x4*>(buf + off_w0[0] + tn * 32 * ROW2 + (kh ? pw1 : pw0));
+  };
+
+  f32x16 acc[4][4];   // [tm][tn]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  u32x4 xf[4][2], aw[4][2], bw[4][2];   // [tm / tn][kh]: one activation set (re-read in place), two weight sets
+  u32x4 ga[16], gb[16];
+  // even step: 4 groups (tm) of 8 MFMAs; per group 2 weight reads, 4 writes, 4 loads, 2 in-place activation reads
+  auto even_step = [&](int s, u32x4 (&cw)[4][2], u32x4 (&nw)[4][2], u32x4 (&gl)[16], u32x4 (&gw)[16]) {
+    const char* nbuf = smem + ((s + 1) & 3) * STAGE2;
+    const int wslot = ((s + 2) >> 1) & 1, u = (s >> 1) + 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mma32_acc(acc[q][0], cw[0][0], xf[q][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      nw[q][0] = read_w(nbuf, q, 0);
+      if (q == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the unit loaded two steps ago
+      write_piece(wslot, 4 * q, gw[4 * q]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][1], cw[1][0], xf[q][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      nw[q][1] = read_w(nbuf, q, 1);
+      write_piece(wslot, 4 * q + 1, gw[4 * q + 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][2], cw[2][0], xf[q][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      write_piece(wslot, 4 * q + 2, gw[4 * q + 2]);
+      write_piece(wslot, 4 * q + 3, gw[4 * q + 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][3], cw[3][0], xf[q][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      gl[4 * q] = load_piece(u, 4 * q);
+      xf[q][0] = read_x(nbuf, q, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][0], cw[0][1], xf[q][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      gl[4 * q + 1] = load_piece(u, 4 * q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][1], cw[1][1], xf[q][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      gl[4 * q + 2] = load_piece(u, 4 * q + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][2], cw[2][1], xf[q][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      gl[4 * q + 3] = load_piece(u, 4 * q + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][3], cw[3][1], xf[q][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      xf[q][1] = read_x(nbuf, q, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the fragment reads and this wave's ds_writes are done
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto odd_step = [&](int s, u32x4 (&cw)[4][2], u32x4 (&nw)[4][2]) {
+    const char* nbuf = smem + ((s + 1) & 3) * STAGE2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      mma32_acc(acc[q][0], cw[0][0], xf[q][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      nw[q][0] = read_w(nbuf, q, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][1], cw[1][0], xf[q][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      nw[q][1] = read_w(nbuf, q, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][2], cw[2][0], xf[q][0]);
+      mma32_acc(acc[q][3], cw[3][0], xf[q][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      xf[q][0] = read_x(nbuf, q, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma32_acc(acc[q][0], cw[0][1], xf[q][1]);
+      mma32_acc(acc[q][1], cw[1][1], xf[q][1]);
+      mma32_acc(acc[q][2], cw[2][1], xf[q][1]);
+      mma32_acc(acc[q][3], cw[3][1], xf[q][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      xf[q][1] = read_x(nbuf, q, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // prologue: units 0 and 1 into the register sets, unit 0 into stage images 0, 1
+#pragma unroll
+  for (int j = 0; j < 16; ++j) gb[j] = load_piece(0, j);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) ga[j] = load_piece(1, j);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) write_piece(0, j, gb[j]);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();   // stages 0 and 1 are complete in LDS
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      aw[f][kh] = read_w(smem, f, kh);
+      xf[f][kh] = read_x(smem, f, kh);
+    }
+  int s = 0;
+  for (; s + 4 <= nt; s += 4) {
+    even_step(s, aw, bw, gb, ga);
+    odd_step(s + 1, bw, aw);
+    even_step(s + 2, aw, bw, ga, gb);
+    odd_step(s + 3, bw, aw);
+  }
+  if (s < nt) {
+    even_step(s, aw, bw, gb, ga);
+    odd_step(s + 1, bw, aw);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  // ---- to the eight-wave kernels' accumulator layout, one 64-column half at a time, and their epilogues ----
+  const int i16 = lane & 15, g = lane >> 4;
+  const bool whole_rows = p.C2 == nullptr && p.res == nullptr && p.vec_store;   // (uniform)
+  auto half = [&](f32x16 (&t0)[4], f32x16 (&t1)[4], int hh) {   // t0[tm], t1[tm]: blocks t = 0 / 1 of half hh
+    f32x4 old[4][8];   // [fn][fm]
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          // X = [X0 X1 X2 X3] (16-lane rows), Y likewise:  32-swap -> [X0 X1 Y0 Y1], [X2 X3 Y2 Y3];  16-swap -> [X0 X2 Y0 Y2], [X1 X3 Y1 Y3]
+          const u32x2_sw r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0[tm][4 * a + b]), __float_as_uint(t1[tm][4 * a + b]), false, false);
+          const u32x2_sw q = __builtin_amdgcn_permlane16_swap(r.x, r.y, false, false);
+          old[a][2 * tm][b] = __uint_as_float(q.x);
+          old[a][2 * tm + 1][b] = __uint_as_float(q.y);
+        }
+    const int wn = 2 * wn2 + hh;
+    if (whole_rows) epilogue_256_bf16_coalesced<1>(p, old, m0, n0, wm, wn, wm * 4 + wn, lane, smem);
+    else epilogue_256<bf16_t>(p, old, m0, n0, wm, wn, i16, g);
+  };
+  {
+    f32x16 t0[4] = {acc[0][0], acc[1][0], acc[2][0], acc[3][0]}, t1[4] = {acc[0][1], acc[1][1], acc[2][1], acc[3][1]};
+    half(t0, t1, 0);
+  }
+  {
+    f32x16 t0[4] = {acc[0][2], acc[1][2], acc[2][2], acc[3][2]}, t1[4] = {acc[0][3], acc[1][3], acc[2][3], acc[3][3]};
+    half(t0, t1, 1);
+  }
+}
+
 }  // namespace
 
 }  // namespace aurora
@@ -420,6 +673,7 @@ extern "C" __attribute__((visibility("hidden"))) int aurora_w4_launch(const void
     (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256w4v<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
+    (void)hipFuncSetAttribute((const void*)linear_kernel_256w4m<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
     (void)hipFuncSetAttribute((const void*)linear_kernel_256w4<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * STAGE2);
@@ -432,6 +686,10 @@ extern "C" __attribute__((visibility("hidden"))) int aurora_w4_launch(const void
     case 5: hipLaunchKernelGGL(linear_kernel_256w4<5>, gr, bl, 5 * STAGE2, as_stream(stream), p); break;
     case 6:   // whole-line register staging: K in units of 64
       if (p.k_tiles % 2 == 0) hipLaunchKernelGGL(linear_kernel_256w4v<0>, gr, bl, 4 * STAGE2, as_stream(stream), p);
+      else hipLaunchKernelGGL(linear_kernel_256w4<4>, gr, bl, 4 * STAGE2, as_stream(stream), p);
+      break;
+    case 7:   // 32x32x16 MFMAs
+      if (p.k_tiles % 2 == 0) hipLaunchKernelGGL(linear_kernel_256w4m<0>, gr, bl, 4 * STAGE2, as_stream(stream), p);
       else hipLaunchKernelGGL(linear_kernel_256w4<4>, gr, bl, 4 * STAGE2, as_stream(stream), p);
       break;
     case 14: hipLaunchKernelGGL((linear_kernel_256w4<4, 1>), gr, bl, 4 * STAGE2, as_stream(stream), p); break;
