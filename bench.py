@@ -321,7 +321,12 @@ def main() -> None:
             raise SystemExit(3)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    control = dist.new_group(backend="gloo") if distributed else None   # host-side agreement between ranks (see below)
+    control = None   # host-side (gloo) group for agreement between ranks that does not depend on RCCL's state (see below)
+    if distributed:
+        try:
+            control = dist.new_group(backend="gloo")
+        except Exception as e:  # noqa: BLE001  -- agreement then runs over the main group, as it did before
+            log(f"no gloo control group ({e!r}); using the main process group")
     bands_error = None
 
     mode = os.environ.get("AURORA_BENCH_MODE", "bands") if distributed else "single"
