@@ -16,7 +16,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "_lib" / "libaurora_hip.so"
-SOURCES = ("runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "embed.hip", "band.hip", "model.hip", "step.hip")
+SOURCES = ("runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "embed.hip", "perceiver_out.hip", "band.hip", "model.hip",
+           "step.hip")
 ARCH = "gfx950"
 
 

@@ -172,6 +172,7 @@ struct PercArgs {
   const void* q; int64_t q_col_stride; const void* kv; void* out;
   int B; int64_t cols_per_b, kv_bstride, kv_lstride; int Lq, Lk, heads;
   const float* pair_guard; float pair_limit;   // fp32 results leave as fp16 pairs iff *pair_guard < pair_limit (else fp32)
+  const float* skip_guard; float skip_limit;   // the launch retires at once iff *skip_guard < skip_limit (null: never)
 };
 
 // A group of HDIM / 4 adjacent lanes owns one (grid column, head): each lane holds 4 of the head's features, so a
@@ -204,6 +205,7 @@ __device__ __forceinline__ float group_sum(float v) {
 template <typename T, int HDIM, int QC, bool FEWK = false>
 __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs p) {
   constexpr int LPG = HDIM / 4;   // lanes per (column, head)
+  if (p.skip_guard != nullptr && *p.skip_guard < p.skip_limit) return;   // (uniform) the re-associated pair does the work
   const int inner = p.heads * HDIM;
   const int64_t n_cols = (int64_t)p.B * p.cols_per_b;
   const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPG;
@@ -500,11 +502,21 @@ extern "C" int aurora_hip_perceiver_attention_ex(const void* q, int64_t q_col_st
                                                  int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
                                                  int Lq, int Lk, int heads, int head_dim, int dtype,
                                                  const float* pair_guard, float pair_limit, void* stream) {
+  return aurora_hip_perceiver_attention_unless(q, q_col_stride, kv, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads,
+                                               head_dim, dtype, pair_guard, pair_limit, nullptr, 0.f, stream);
+}
+
+extern "C" int aurora_hip_perceiver_attention_unless(const void* q, int64_t q_col_stride, const void* kv, void* out,
+                                                     int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
+                                                     int Lq, int Lk, int heads, int head_dim, int dtype,
+                                                     const float* pair_guard, float pair_limit, const float* skip_guard,
+                                                     float skip_limit, void* stream) {
   AURORA_CHECK_ARG(dtype == AURORA_F32 || dtype == AURORA_BF16, "perceiver_attention: bad dtype");
   AURORA_CHECK_ARG(Lq > 0 && Lk > 0 && heads > 0 && B > 0 && cols_per_b > 0, "perceiver_attention: empty problem");
   AURORA_CHECK_ARG(pair_guard == nullptr || (dtype == AURORA_F32 && (heads * head_dim) % 32 == 0 && head_dim % 8 == 0),
                    "perceiver_attention: fp16-pair output needs fp32 and heads * head_dim %% 32 == 0");
-  PercArgs p{q, q_col_stride, kv, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads, pair_guard, pair_limit};
+  PercArgs p{q, q_col_stride, kv, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads, pair_guard, pair_limit, skip_guard,
+             skip_limit};
   const int64_t items = (int64_t)B * cols_per_b * heads * (head_dim / 4);   // one lane per 4 features of a head
   const dim3 grid(blocks_for(items, 256)), block(256);
 #define AURORA_PERC(TT, HDIM)                                                                                              \

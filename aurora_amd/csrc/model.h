@@ -214,6 +214,7 @@ struct aurora_hip_model {
   int fuse_ln = 1;
   bool split_attention = false;
   bool qkv_planes = true;   // bf16 blocks: q | k | v leave the qkv linear one attention head per plane (aurora_hip_linear_planes)
+  bool reassoc_out = true;  // decoder de-aggregation: to_out of the three value rows per column, combined in registers (perceiver_out.hip)
 
   // per step
   aurora::DevBuf abs_enc, dyn_planes, ctx_max;
@@ -267,7 +268,7 @@ typedef aurora_hip_model Model;
 // Kernel kinds of the per-launch timing; `work` is the algorithmic work of a launch: FLOPs for the linears, bytes
 // (q, k, v read + o written once) for the window attention, 0 elsewhere.
 enum Kind { K_LINEAR_BF16, K_LINEAR_F32, K_WINDOW_ATTENTION, K_LAYERNORM, K_MERGE_LN, K_SPLIT_LN, K_PATCHIFY,
-            K_PERCEIVER_ATTENTION, K_ASSEMBLE, K_UNPATCHIFY, K_COPY2D, K_ABSMAX, K_LINEAR_LN, K_GATHER, K_COUNT };
+            K_PERCEIVER_ATTENTION, K_ASSEMBLE, K_UNPATCHIFY, K_COPY2D, K_ABSMAX, K_LINEAR_LN, K_GATHER, K_PERCEIVER_OUT, K_COUNT };
 
 hipEvent_t take_event(Model& m);
 

@@ -1235,7 +1235,7 @@ extern "C" int aurora_hip_step(aurora_hip_model* mp, const aurora_hip_step_io* i
 namespace {
 const char* const KIND_NAMES[K_COUNT] = {"linear_bf16", "linear_f32", "window_attention_bf16", "layernorm", "merge_ln",
                                          "split_ln", "patchify", "perceiver_attention", "assemble_tokens", "unpatchify",
-                                         "copy2d", "absmax", "linear_layernorm_bf16", "gather_rows"};
+                                         "copy2d", "absmax", "linear_layernorm_bf16", "gather_rows", "perceiver_out"};
 }
 
 extern "C" int aurora_hip_profile_begin(aurora_hip_model* m, uint32_t kind_mask) {

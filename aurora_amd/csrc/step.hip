@@ -52,7 +52,18 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     const size_t att_off = (std::max(unit, kvq_bytes) + 255) & ~size_t(255);
     const size_t hid_row = (size_t)ly.hidden * 4;
     const size_t hid_min = (size_t)std::min<int64_t>(n_rows, 256) * hid_row;   // at least one row tile of the hidden layer
-    const size_t s_bytes = std::max(att_in_y ? std::max(unit, kvq_bytes) : att_off + att_bytes, hid_min);
+    // The decoder's de-aggregation (first layer: queries shared by all columns, three keys per column) runs RE-ASSOCIATED
+    // (perceiver_out.hip): to_out of the three value rows per column and head, then the Lq x 3 convex combinations per head
+    // in registers -- the attention output and its Lq-row `to_out` GEMM do not exist.  Its inputs: the softmax weights P
+    // (behind to_out's result in the scratch region) and the value rows as fp16 pairs (in the result region, until fc2
+    // writes there).  Two fp16 terms: decided on the device by the guard of the linear it replaces.
+    const int64_t n_cols = (int64_t)B * cols;
+    const bool att_pairs = ly.to_out_s != nullptr && inner % 32 == 0;
+    const bool reassoc = m.reassoc_out && i == 0 && att_pairs && att_in_y && Lk <= Lq && inner <= Dd && ly.f16_mode == 2 &&
+                         aurora_hip_perceiver_out_supported(Lq, Lk, heads, ly.head_dim, Dd) != 0;
+    const size_t p_off = (unit + 255) & ~size_t(255), p_bytes = reassoc ? (size_t)n_cols * heads * 64 * 4 : 0;
+    const size_t s_bytes = std::max(std::max(att_in_y ? std::max(unit, kvq_bytes) : att_off + att_bytes, hid_min),
+                                    reassoc ? p_off + p_bytes : (size_t)0);
     char* S = (char*)m.arena.take(s_bytes);
     float* kv = (float*)S;
     // guarded linears with pre-split weights: the two-term launch runs iff the guard holds, the three-term one (fp32
@@ -91,13 +102,33 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     // |att| <= max |v| <= (largest L1 row norm of W_v) * max |ctx|: same guard, tighter limit.  With pre-split to_out
     // weights the attention writes fp16 pairs iff that guard holds, and to_out multiplies them without splitting anything.
     const float lim_out = (F16_SAFE / ly.v_l1 - g_c) / g_a;
-    const bool att_pairs = ly.to_out_s != nullptr && inner % 32 == 0;
-    timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] {
-      return aurora_hip_perceiver_attention_ex(q, q_stride, kv, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim,
-                                               AURORA_F32, att_pairs ? ctx_max : nullptr, lim_out, L.stream);
-    });
     float* o = (float*)S;   // (k | v and q are dead)
-    guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, lim_out, att_pairs);
+    if (reassoc) {
+      float* P = (float*)(S + p_off);
+      void* Vp = y;
+      timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] {
+        return aurora_hip_perceiver_probs(q, kv, P, Vp, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim, ctx_max, lim_out,
+                                          L.stream);
+      });
+      // (work: the three value rows of a column through to_out, and the Lq x Lk combinations per head)
+      timed(m, L.stream, K_PERCEIVER_OUT, 2.0 * (double)n_cols * Lk * Dd * inner + 2.0 * (double)n_rows * Dd * heads * Lk, [&] {
+        return aurora_hip_perceiver_out(Vp, ly.to_out_s, inner, P, nullptr, o, Dd, n_cols, Lq, Lk, heads, ly.head_dim, Dd, ctx_max,
+                                        lim_out, L.stream);
+      });
+      // Values outside fp16's range (the same word decides, on the device): the plain pair -- attention output in fp32, to_out
+      // on three bf16 terms -- runs instead; inside the range both launches retire at once.
+      timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] {
+        return aurora_hip_perceiver_attention_unless(q, q_stride, kv, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads,
+                                                     ly.head_dim, AURORA_F32, nullptr, 0.f, ctx_max, lim_out, L.stream);
+      });
+      L.linear(att, inner, ly.to_out, inner, nullptr, o, Dd, n_rows, Dd, inner, AURORA_F32, 0, nullptr, 0, nullptr, 0, 1, ctx_max, lim_out);
+    } else {
+      timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] {
+        return aurora_hip_perceiver_attention_ex(q, q_stride, kv, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim,
+                                                 AURORA_F32, att_pairs ? ctx_max : nullptr, lim_out, L.stream);
+      });
+      guarded(att, inner, ly.to_out, ly.to_out_s, o, Dd, n_rows, Dd, inner, lim_out, att_pairs);
+    }
     // The MLP in the fp16-pair layout end to end: the LayerNorm writes its result already split (and ONLY split), fc1
     // reads that and writes its GELU'd result split, fc2 reads that -- neither GEMM splits anything -- and the LayerNorm
     // behind the MLP takes the split array as its residual.

@@ -98,6 +98,14 @@ _SIGNATURES = {
     "aurora_hip_perceiver_attention_ex": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64,
                                                   c_int64, c_int64, c_int, c_int, c_int, c_int, c_int,
                                                   c_void_p, c_float, c_void_p]),
+    "aurora_hip_perceiver_attention_unless": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64,
+                                                      c_int64, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                                      c_void_p, c_float, c_void_p, c_float, c_void_p]),
+    "aurora_hip_perceiver_out_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "aurora_hip_perceiver_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64,
+                                           c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
+    "aurora_hip_perceiver_out": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                         c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
     "aurora_hip_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "aurora_hip_unpatchify": (c_int, [c_void_p, c_int64, ctypes.POINTER(UnpatchVar), c_int, c_int,
@@ -503,15 +511,46 @@ def patchify(desc: list[PatchVar], out: torch.Tensor, k_offset: int, k_total: in
 
 def perceiver_attention(q: torch.Tensor, q_col_stride: int, kv: torch.Tensor, out: torch.Tensor,
                         B: int, cols_per_b: int, kv_bstride: int, kv_lstride: int, Lq: int, Lk: int,
-                        heads: int, head_dim: int, pair_guard=None) -> torch.Tensor:
-    """`pair_guard=(word, limit)`: fp32 results are written as fp16 pairs iff word[0] < limit (decided on the device)."""
+                        heads: int, head_dim: int, pair_guard=None, skip_guard=None) -> torch.Tensor:
+    """`pair_guard=(word, limit)`: fp32 results are written as fp16 pairs iff word[0] < limit (decided on the device).
+    `skip_guard=(word, limit)`: the launch retires at once iff word[0] < limit."""
     assert q.is_contiguous() and kv.is_contiguous() and out.is_contiguous()
     assert q.dtype == kv.dtype == out.dtype
     word, limit = pair_guard if pair_guard is not None else (None, 0.0)
+    sword, slimit = skip_guard if skip_guard is not None else (None, 0.0)
     with _Timed("perceiver_attention", 0.0):
-        _check(load().aurora_hip_perceiver_attention_ex(_ptr(q), q_col_stride, _ptr(kv), _ptr(out), B,
-                                                        cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads,
-                                                        head_dim, dtype_code(q.dtype), _ptr(word), float(limit), _stream()))
+        _check(load().aurora_hip_perceiver_attention_unless(_ptr(q), q_col_stride, _ptr(kv), _ptr(out), B,
+                                                            cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads,
+                                                            head_dim, dtype_code(q.dtype), _ptr(word), float(limit),
+                                                            _ptr(sword), float(slimit), _stream()))
+    return out
+
+
+def perceiver_probs(q: torch.Tensor, kv: torch.Tensor, B: int, cols_per_b: int, kv_bstride: int, kv_lstride: int,
+                    Lq: int, Lk: int, heads: int, head_dim: int, guard=None):
+    """Softmax weights P (n_cols, heads, 64) and the value rows as fp16 pairs Vp (n_cols * Lk, inner) of the
+    re-associated decoder attention (aurora_hip_perceiver_probs)."""
+    assert q.is_contiguous() and kv.is_contiguous() and q.dtype == kv.dtype == torch.float32
+    n_cols, inner = B * cols_per_b, heads * head_dim
+    P = torch.zeros((n_cols, heads, 64), device=kv.device, dtype=torch.float32)
+    Vp = torch.zeros((n_cols * Lk, inner), device=kv.device, dtype=torch.float32)
+    word, limit = guard if guard is not None else (None, 0.0)
+    with _Timed("perceiver_attention", 0.0):
+        _check(load().aurora_hip_perceiver_probs(_ptr(q), _ptr(kv), _ptr(P), _ptr(Vp), B, cols_per_b, kv_bstride,
+                                                 kv_lstride, Lq, Lk, heads, head_dim, _ptr(word), float(limit), _stream()))
+    return P, Vp
+
+
+def perceiver_out(Vp: torch.Tensor, w_pairs: torch.Tensor, P: torch.Tensor, out: torch.Tensor, n_cols: int, Lq: int,
+                  Lk: int, heads: int, head_dim: int, bias: Optional[torch.Tensor] = None, guard=None) -> torch.Tensor:
+    """out[col * Lq + l] = sum_h sum_j P[col, h, l, j] W[:, h] Vp[col * Lk + j, h] (aurora_hip_perceiver_out)."""
+    assert Vp.is_contiguous() and w_pairs.is_contiguous() and P.is_contiguous() and out.is_contiguous()
+    N = out.shape[1]
+    word, limit = guard if guard is not None else (None, 0.0)
+    with _Timed("perceiver_out", 2.0 * n_cols * Lk * N * heads * head_dim):
+        _check(load().aurora_hip_perceiver_out(_ptr(Vp), _ptr(w_pairs), w_pairs.shape[1], _ptr(P), _ptr(bias), _ptr(out),
+                                               out.stride(0), n_cols, Lq, Lk, heads, head_dim, N, _ptr(word), float(limit),
+                                               _stream()))
     return out
 
 
@@ -634,7 +673,7 @@ class HipPlanInfo(ctypes.Structure):
 
 PROFILE_KINDS = ("linear_bf16", "linear_f32", "window_attention_bf16", "layernorm", "merge_ln", "split_ln", "patchify",
                  "perceiver_attention", "assemble_tokens", "unpatchify", "copy2d", "absmax", "linear_layernorm_bf16",
-                 "gather_rows")
+                 "gather_rows", "perceiver_out")
 
 _SIGNATURES.update({
     "aurora_hip_profile_begin": (c_int, [c_void_p, ctypes.c_uint32]),

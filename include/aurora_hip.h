@@ -280,6 +280,33 @@ int aurora_hip_perceiver_attention_ex(const void* q, int64_t q_col_stride, const
                                       int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
                                       int Lq, int Lk, int heads, int head_dim, int dtype,
                                       const float* pair_guard, float pair_limit, void* stream);
+/* The same as one half of a device-side choice between this kernel and the re-associated pair below: the launch retires
+ * at once iff *skip_guard < skip_limit (null: never). */
+int aurora_hip_perceiver_attention_unless(const void* q, int64_t q_col_stride, const void* kv, void* out,
+                                          int B, int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride,
+                                          int Lq, int Lk, int heads, int head_dim, int dtype,
+                                          const float* pair_guard, float pair_limit, const float* skip_guard,
+                                          float skip_limit, void* stream);
+
+/* ---- the decoder's level de-aggregation, re-associated (perceiver.py:141-152 + its `to_out`, decoder.py:156-166, 225-231)
+ * With queries shared by all columns (q_col_stride == 0) and Lk = 3 keys per column,
+ *     to_out(concat_h sum_j p[l,h,j] v[j,h,:]) = sum_h sum_j p[l,h,j] (W_out[:, h-th 64 columns] v[j,h,:]):
+ * the three values of a column are projected per head (Lk rows per column instead of Lq) and combined with the softmax
+ * weights in registers; the attention output is never written.  fp32-grade: two fp16 terms per operand (the values must be
+ * inside fp16's range: the caller's guard), fp32 weights p, fp32 accumulation.
+ *   _probs: P[col][head][l][4] = softmax_j(q_l . k_j / 8) (fp32, 64 floats per (col, head), zero-padded) and
+ *           Vp[col * 3 + j][inner] = v_j in the fp16-pair layout (AURORA_F32_A_SPLIT); q, kv as aurora_hip_perceiver_attention.
+ *   _out:   out[col * Lq + l][0..N) = sum_h sum_j P[col][h][l][j] W_pairs[:, 64 h .. 64 h + 63] Vp[col * 3 + j][64 h ..] + bias;
+ *           W_pairs: [N][ldw] pre-split weights scaled by 2^6 (aurora_hip_split_f16 with scale 64).
+ * Both retire at once unless *guard < guard_limit (null: always run).  Built for Lq in {3, 4, 13}, Lk = 3, head_dim 64,
+ * N % 128 == 0: aurora_hip_perceiver_out_supported says whether a shape is. */
+int aurora_hip_perceiver_out_supported(int Lq, int Lk, int heads, int head_dim, int N);
+int aurora_hip_perceiver_probs(const float* q, const float* kv, float* P, void* Vp, int B, int64_t cols_per_b,
+                               int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads, int head_dim,
+                               const float* guard, float guard_limit, void* stream);
+int aurora_hip_perceiver_out(const void* Vp, const void* W_pairs, int64_t ldw, const float* P, const float* bias,
+                             float* out, int64_t ldo, int64_t n_cols, int Lq, int Lk, int heads, int head_dim, int N,
+                             const float* guard, float guard_limit, void* stream);
 
 /* ---- token assembly at the encoder output -------------------------------------------------
  * x[b][c][l][:] = (c == 0 ? surf[b][l][:] : agg[(b*L + l)*(Cl-1) + c-1][:])
@@ -554,8 +581,8 @@ int aurora_hip_band_plan(const int32_t res[3], const int32_t window[3], int shif
 /* Per-launch timing of the handle's own kernels: between _begin and _end every launch of a kernel kind whose bit is set
  * in kind_mask (bit i = entry i of the table _end returns: linear_bf16, linear_f32, window_attention_bf16, layernorm,
  * merge_ln, split_ln, patchify, perceiver_attention, assemble_tokens, unpatchify, copy2d, absmax, linear_layernorm_bf16,
- * gather_rows) is bracketed by a HIP event pair on the launch stream.  _end synchronises the device and fills `out`
- * (capacity >= 14): launches, summed
+ * gather_rows, perceiver_out) is bracketed by a HIP event pair on the launch stream.  _end synchronises the device and
+ * fills `out` (capacity >= 15): launches, summed
  * milliseconds and summed algorithmic work (FLOPs for the linears, bytes for the window attention) per kind.  This is
  * what bench.py's `roofline` is computed from.  An event pair keeps a launch from overlapping its neighbours. */
 typedef struct aurora_hip_profile_entry {

@@ -713,6 +713,65 @@ def test_perceiver_attention(Lq, Lk, hd):
     assert relerr(out, ref) < 3e-6
 
 
+def _reassoc_reference(q, kv, w, B, cols, Lq, Lk, heads, hd):
+    """fp64: F.scaled_dot_product_attention over the Lk keys of every column, then F.linear with to_out's weight
+    (perceiver.py:141-152) -- rows (b, col, l)."""
+    inner = heads * hd
+    kvr = kv.reshape(B, Lk, cols, 2, heads, hd).permute(3, 0, 2, 4, 1, 5)  # (2, B, cols, heads, Lk, hd)
+    qq = q.reshape(Lq, heads, hd).permute(1, 0, 2)[None, None].expand(B, cols, -1, -1, -1)
+    att = F.scaled_dot_product_attention(qq, kvr[0], kvr[1])  # (B, cols, heads, Lq, hd)
+    return F.linear(att.permute(0, 1, 3, 2, 4).reshape(B * cols * Lq, inner), w)
+
+
+# (the production decoder: 13 levels, 3 latent keys, 16 x 64, D = 1024; a ragged column count; the small level counts)
+@pytest.mark.parametrize("Lq,heads,N,cols,B", [(13, 16, 1024, 300, 1), (13, 16, 1024, 77, 2), (4, 2, 128, 50, 1), (3, 4, 256, 33, 2)])
+def test_perceiver_out_reassociated_equals_attention_then_to_out(Lq, heads, N, cols, B):
+    L = lib()
+    Lk, hd = 3, 64
+    inner = heads * hd
+    q = rnd(Lq, inner, seed=1)
+    kv = rnd(B * Lk * cols, 2 * inner, seed=2)   # rows (b, j, col)
+    w = rnd(N, inner, seed=3, scale=inner ** -0.5)
+    ref = _reassoc_reference(q, kv, w, B, cols, Lq, Lk, heads, hd)
+    assert L.load().aurora_hip_perceiver_out_supported(Lq, Lk, heads, hd, N) == 1
+    P, Vp = L.perceiver_probs(q.float().to(DEV), kv.float().to(DEV), B, cols, Lk * cols, cols, Lq, Lk, heads, hd)
+    w_pairs = L.split_f16(w.float().to(DEV), scale=64.0)
+    out = torch.full((B * cols * Lq, N), float("nan"), device=DEV)
+    L.perceiver_out(Vp, w_pairs, P, out, B * cols, Lq, Lk, heads, hd)
+    torch.cuda.synchronize()
+    # the weights: softmax over the three keys, [l][4] per (column, head), zero-padded
+    kvr = kv.reshape(B, Lk, cols, 2, heads, hd)
+    sc = torch.einsum("lhd,bjchd->bchlj", q.reshape(Lq, heads, hd), kvr[:, :, :, 0]) / 8.0
+    p_ref = torch.softmax(sc, dim=-1).reshape(B * cols, heads, Lq, Lk)
+    p_got = P.reshape(B * cols, heads, 16, 4).cpu().double()
+    assert (p_got[:, :, :Lq, :Lk] - p_ref).abs().max().item() < 1e-6
+    assert p_got[:, :, Lq:].abs().max().item() == 0 and p_got[:, :, :, Lk:].abs().max().item() == 0
+    # the values as fp16 pairs: exactly what the splitting kernel makes of them, rows (col, j)
+    v = kvr[:, :, :, 1].permute(0, 2, 1, 3, 4).reshape(B * cols * Lk, inner).float().to(DEV)
+    assert torch.equal(Vp, L.split_f16(v))
+    assert relerr(out, ref) < 3e-6
+
+
+@pytest.mark.parametrize("holds", [True, False])
+def test_perceiver_out_pair_and_plain_pair_follow_the_guard(holds):
+    """The device word picks exactly one of {probs + out, attention + (three-term) to_out}; the other pair retires."""
+    L = lib()
+    B, cols, Lq, Lk, heads, hd, N = 1, 64, 13, 3, 16, 64, 1024
+    inner = heads * hd
+    q = rnd(Lq, inner, seed=1).float().to(DEV)
+    kv = rnd(Lk * cols, 2 * inner, seed=2).float().to(DEV)
+    word = torch.tensor([1.0 if holds else 3.0], device=DEV)
+    P, Vp = L.perceiver_probs(q, kv, B, cols, Lk * cols, cols, Lq, Lk, heads, hd, guard=(word, 2.0))
+    out = torch.full((cols * Lq, N), -7.0, device=DEV)
+    w_pairs = L.split_f16(rnd(N, inner, seed=3, scale=inner ** -0.5).float().to(DEV), scale=64.0)
+    L.perceiver_out(Vp, w_pairs, P, out, cols, Lq, Lk, heads, hd, guard=(word, 2.0))
+    att = torch.full((cols * Lq, inner), -7.0, device=DEV)
+    L.perceiver_attention(q, 0, kv, att, B, cols, cols * Lk, cols, Lq, Lk, heads, hd, skip_guard=(word, 2.0))
+    torch.cuda.synchronize()
+    assert bool((P != 0).any()) == holds and bool((out != -7.0).all()) == holds
+    assert bool((att == -7.0).all()) == holds
+
+
 def test_assemble_tokens():
     L = lib()
     B, Cl, Lp, D = 2, 4, 30, 64
