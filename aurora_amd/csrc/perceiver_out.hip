@@ -31,6 +31,7 @@
 // Waves 4-7 run one phase behind waves 0-3 (their SIMD partners): a SIMD's matrix pipe belongs to one wave while the
 // other does the LDS / VALU work.
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -63,10 +64,25 @@ __device__ __forceinline__ f32x4 mma_f16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
-// acc += p[lane K of this lane's row of 16] * u  (one VALU instruction)
+// a[nt] += p[lane K of this lane's row of 16] * u[nt], nt = 0..3: one broadcast (v_mov_b32_dpp row_newbcast -- cross-lane VALU
+// operations run at half rate, so the weight is broadcast once, not folded into each FMA) and four plain FMAs.  One asm
+// statement: hipcc would pad a state between dependent statements, and packs adjacent C++ FMAs into v_pk_fma_f32 pairs.
+// `w` is the caller's ONE scratch register, read-write in every statement and so live from the first to the last of them:
+// as a per-statement output hipcc put it into the dead fourth element of whatever product tile the MFMA in front had just
+// been issued into -- the matrix pipe then overwrote the weight between two FMAs (the hazard recogniser does not look
+// into asm statements).  A value that is live across an MFMA cannot share a register with its result.
 template <int K>
-__device__ __forceinline__ void fmac_bcast(float& acc, float p, float u) {
-  asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(p), "v"(u), "i"(K));
+__device__ __forceinline__ void fma4_bcast(float& a0, float& a1, float& a2, float& a3, float& w, float p, float u0, float u1,
+                                           float u2, float u3) {
+  asm volatile("v_mov_b32_dpp %4, %5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f32 %0, %4, %6\n\tv_fmac_f32 %1, %4, %7\n\tv_fmac_f32 %2, %4, %8\n\tv_fmac_f32 %3, %4, %9"
+               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w)
+               : "v"(p), "v"(u0), "v"(u1), "v"(u2), "v"(u3), "i"(K));
+}
+
+template <typename F, int... I>
+__device__ __forceinline__ void unroll_idx(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
 }
 
 // XCD-aware order: each XCD owns a contiguous range of tiles, the n-tiles of a column tile adjacent (its values are then
@@ -80,7 +96,7 @@ template <int LQ>
 __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const PercOutArgs p) {
   static_assert(LQ >= 1 && LQ * 4 <= PO_PS, "level queries per column");
   constexpr int LK = 3;
-  constexpr int PREGS = (LQ * 4 + 15) / 16;
+  constexpr int PREGS = (LQ * 2 + 15) / 16;   // P of a (column, head): [l][2] = the weights of keys 0 and 1
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.guard != nullptr && !(*p.guard < p.guard_limit)) return;   // (uniform)
   const int tid = threadIdx.x;
@@ -95,50 +111,45 @@ __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const Perc
   const int heads = p.heads;
 
   // ---- LDS-DMA sources: per K-stage 2 pieces of the value tile, 2 of the weight tile; per head 1 piece of P.
-  //      Uniform 64-bit bases (scalar registers) + one 32-bit offset per lane and piece. ----
-  const int64_t cols_here = p.n_cols - col0 < PO_COLS ? p.n_cols - col0 : PO_COLS;   // (uniform) columns of this tile that exist
-  const char* const base_v = p.V + col0 * LK * p.ldv_b;
-  const char* const base_w = p.W + (int64_t)n0 * p.ldw_b;
-  const char* const base_p = reinterpret_cast<const char*>(p.P) + col0 * heads * (PO_PS * 4);
-  uint32_t vo_v[2], vo_w[2], vo_p;
-  // (row 4 c + 3 of a column does not exist: its lanes stay out of the DMA, what LDS holds there is never used.  The same
-  //  lanes in both pieces: piece r covers rows 64 r + (tid >> 3))
-  const bool v_on = ((tid >> 3) & 3) < LK;
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int row = r * 64 + (tid >> 3), c = tid & 7;
-    const int j = row & 3;
-    int cl = row >> 2;
-    cl = cl < (int)cols_here ? cl : (int)cols_here - 1;
-    vo_v[r] = (uint32_t)((cl * LK + (j < LK ? j : 0)) * (int)p.ldv_b + ((c ^ (row & 7)) << 4));
-    // LDS row t of the weight tile holds feature 64 (t >> 6) + 4 (t & 15) + ((t >> 4) & 3)
-    const int feat = (row & 64) + 4 * (row & 15) + ((row >> 4) & 3);
-    vo_w[r] = (uint32_t)(feat * (int)p.ldw_b + ((c ^ (row & 7)) << 4));
-  }
+  //      Through buffer descriptors (buffer_load ... lds): one 32-bit offset per lane and operand, everything else -- the
+  //      K-stage, the second piece of an operand (64 tile rows further on) -- is a scalar offset: no vector address
+  //      arithmetic per piece.  The descriptors end with the arrays: a ragged last tile reads zeros behind the last column. ----
+  auto descriptor = [](const char* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff), 0x00020000);
+  };
+  const int64_t cols_left = p.n_cols - col0;
+  const __amdgpu_buffer_rsrc_t rs_v = descriptor(p.V + col0 * LK * p.ldv_b, cols_left * LK * p.ldv_b);
+  const __amdgpu_buffer_rsrc_t rs_w = descriptor(p.W + (int64_t)n0 * p.ldw_b, (int64_t)PO_N * p.ldw_b);
+  const __amdgpu_buffer_rsrc_t rs_p = descriptor(reinterpret_cast<const char*>(p.P) + col0 * heads * (PO_PS * 4),
+                                                  cols_left * heads * (PO_PS * 4));
+  uint32_t vo_v, vo_w, vo_p;
   {
-    int cl = tid >> 4;
-    cl = cl < (int)cols_here ? cl : (int)cols_here - 1;
-    vo_p = (uint32_t)(cl * heads * (PO_PS * 4) + (tid & 15) * 16);
+    // (row 4 c + 3 of a column does not exist: its lanes fetch key 2 again -- the same cache lines as their neighbours' --,
+    //  what LDS holds there is never used.  NOT masked out of the DMA: hipcc duplicates the code behind a divergent branch
+    //  per lane set, and the wave's count of outstanding pieces, which the counted waits below rely on, changes with it.)
+    const int row = tid >> 3, c = tid & 7, j = row & 3;
+    vo_v = (uint32_t)(((row >> 2) * LK + (j < LK ? j : LK - 1)) * (int)p.ldv_b + ((c ^ (row & 7)) << 4));
+    // LDS row t of the weight tile holds feature 64 (t >> 6) + 4 (t & 15) + ((t >> 4) & 3)
+    vo_w = (uint32_t)((4 * (row & 15) + ((row >> 4) & 3)) * (int)p.ldw_b + ((c ^ (row & 7)) << 4));
+    vo_p = (uint32_t)((tid >> 4) * heads * (PO_PS * 4) + (tid & 15) * 16);
   }
+  const int v_half = 16 * LK * (int)p.ldv_b, w_half = 64 * (int)p.ldw_b;   // rows 64.. of a tile: 16 columns / 64 features on
   char* const pbase = smem + PO_NST * PO_STAGE;
-  auto stage_head = [&](int h) {   // both K-stages of head h and its tile of P: 9 LDS-DMA instructions per lane
+  // K-stage s = 2 h + ks of head h: 2 value pieces, 2 weight pieces; the even stage of a head also carries the head's tile of P
+  auto stage_in = [&](int st) {
+    char* base = smem + (st & (PO_NST - 1)) * PO_STAGE;
+    const int koff = st * PO_ROWB;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      char* base = smem + (((2 * h + ks) & (PO_NST - 1))) * PO_STAGE;
-      const int64_t koff = (int64_t)(2 * h + ks) * PO_ROWB;
-      if (v_on) {
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_ptr_t)(base + (r * PO_THREADS + wave * 64) * 16), 16, vo_v, koff + r * v_half, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_v + koff + vo_v[r]),
-                                           (lds_ptr_t)(base + (r * PO_THREADS + wave * 64) * 16), 16, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_w + koff + vo_w[r]),
-                                         (lds_ptr_t)(base + PO_OPER + (r * PO_THREADS + wave * 64) * 16), 16, 0, 0);
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(base + PO_OPER + (r * PO_THREADS + wave * 64) * 16), 16, vo_w,
+                                               koff + r * w_half, 0, 0);
+    if ((st & 1) == 0) {   // (uniform)
+      const int h = st >> 1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (lds_ptr_t)(pbase + (h & 1) * PO_PTILE + wave * 1024), 16, vo_p, h * (PO_PS * 4), 0, 0);
     }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_p + (int64_t)h * (PO_PS * 4) + vo_p),
-                                     (lds_ptr_t)(pbase + (h & 1) * PO_PTILE + wave * 1024), 16, 0, 0);
   };
 
   // ---- fragment read offsets inside a K-stage (pair layout: chunk g = high halves of k = 8g..8g+7, chunk g + 4 = remainders).
@@ -160,152 +171,143 @@ __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const Perc
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int l = 0; l < LQ; ++l) out[mt][nt][l] = 0.f;
-  // (head 0's X_A combines "the previous head": zeros times zeros -- a branch around it would make hipcc keep two copies of
-  //  the 104 accumulators and move them every iteration)
-  f32x4 U[2][4];
-  float pr[2][PREGS];
+  // Two sets of products and weights, A and B: an even head combines A (the previous head's) while it multiplies into B, an
+  // odd head the other way round (no moves; heads is even).  Head 0 combines zeros times zeros -- a branch around it would
+  // make hipcc keep two copies of the 104 accumulators and move them every iteration.
+  f32x4 UA[2][4], UB[2][4];
+  float prA[2][PREGS], prB[2][PREGS];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) U[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 4; ++nt) UA[mt][nt] = UB[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < PREGS; ++c) pr[mt][c] = 0.f;
+    for (int c = 0; c < PREGS; ++c) prA[mt][c] = prB[mt][c] = 0.f;
   }
 
-  struct Frags { u32x4 vh[2][2], vl[2][2], wh[2][2], wl[2][2]; };   // [mt][ks], [nt - nt0][ks]
-  auto read_frags = [&](int h, auto NT0, Frags& f) {
-    constexpr int nt0 = decltype(NT0)::value;
+  // The value rows of a column arrive as (v0 - v2, v1 - v2, v2) and the weights as (p0, p1) for level 0, (p0 - p0[0], p1 - p1[0])
+  // for the others (perceiver_probs_kernel): with p0 + p1 + p2 = 1,
+  //     sum_j p_j U_j  =  U'_2 + p0 U'_0 + p1 U'_1     (U' the products of those rows)
+  // -- two FMAs per level instead of three --, level 0 collects the U'_2 of all heads, and the other levels accumulate their
+  // DIFFERENCE to level 0, added at the end: no separate accumulator for the level-independent part.
+  float wtmp = 0.f;   // the broadcast weight of fma4_bcast
+  // One (level, key) pair of the combine of row fragment MT: element e of 2 LQ, key outermost (an accumulator comes back
+  // LQ pairs later): one broadcast of the weight, four FMAs.
+  auto pair_one = [&](f32x4 (&U)[2][4], float (&pr)[2][PREGS], auto MT, auto E) {
+    constexpr int mt = decltype(MT)::value, e = decltype(E)::value;
+    constexpr int j = e / LQ, l = e % LQ, idx = l * 2 + j;
+    fma4_bcast<idx & 15>(out[mt][0][l], out[mt][1][l], out[mt][2][l], out[mt][3][l], wtmp, pr[mt][idx >> 4], U[mt][0][j],
+                         U[mt][1][j], U[mt][2][j], U[mt][3][j]);
+  };
+  auto base_add = [&](f32x4 (&U)[2][4], auto MT) {
+    constexpr int mt = decltype(MT)::value;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const char* buf = smem + ((2 * h + ks) & (PO_NST - 1)) * PO_STAGE;
+    for (int nt = 0; nt < 4; ++nt) out[mt][nt][0] += U[mt][nt][2];
+  };
+  // One phase = one K-stage (32 of a head's 64) per wave: 12 fragment reads (+ the head's weights), the LDS-DMA of a later
+  // stage, then 24 MFMAs into Un with the 2 LQ (level, key) pairs of row fragment `ks` of U between them (one broadcast + four
+  // FMAs each: the matrix pipe works on an instruction for 16 cycles, the wave issues the FMAs meanwhile).  Smallest terms
+  // first; consecutive MFMAs go to different accumulators.  A barrier ends the phase; waves 4-7 run one phase behind
+  // waves 0-3, their SIMD partners.
+  // Ring (a wave's phase q runs at time q for the early half, q + 1 for the late one): stage st is read at times st / st + 1;
+  // the early half issues stage st + 2 in phase st, the late half stage st + 3 -- both at time st / st + 1 into slots whose
+  // last reader finished a barrier before --; at the end of a phase everything but the pieces just issued has landed, so a
+  // stage is complete a barrier before its first reader.  P of head h travels with stage 2 h.
+  // Measured (s_memtime stamps, 0.25 degree shape): a phase takes ~2,080 cycles -- reads + DMA issue 400-600 (early half) /
+  // ~1,000 (late half, beside its partner's computing), computing 810-890 (158 instructions: a wave issues one every ~5
+  // cycles), then the early half waits ~600 at the barrier.  A schedule of two half-phases per stage (reads + 8 MFMAs |
+  // 16 MFMAs + DMA) measured 5 % slower.
+  constexpr int NF = 2 * LQ;   // (level, key) pairs per row fragment
+  const int n_st = 2 * heads;
+  auto phase = [&](int st, auto KS, f32x4 (&U)[2][4], float (&pr)[2][PREGS], f32x4 (&Un)[2][4], float (&prn)[2][PREGS]) {
+    constexpr int ks = decltype(KS)::value;
+    const char* buf = smem + (st & (PO_NST - 1)) * PO_STAGE;
+    u32x4 vh[2], vl[2], wh[4], wl[4];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        f.vh[mt][ks] = *reinterpret_cast<const u32x4*>(buf + off_v[0] + mt * 16 * PO_ROWB);
-        f.vl[mt][ks] = *reinterpret_cast<const u32x4*>(buf + off_v[1] + mt * 16 * PO_ROWB);
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        f.wh[q][ks] = *reinterpret_cast<const u32x4*>(buf + off_w[0] + (nt0 + q) * 16 * PO_ROWB);
-        f.wl[q][ks] = *reinterpret_cast<const u32x4*>(buf + off_w[1] + (nt0 + q) * 16 * PO_ROWB);
-      }
+    for (int mt = 0; mt < 2; ++mt) {
+      vh[mt] = *reinterpret_cast<const u32x4*>(buf + off_v[0] + mt * 16 * PO_ROWB);
+      vl[mt] = *reinterpret_cast<const u32x4*>(buf + off_v[1] + mt * 16 * PO_ROWB);
     }
-  };
-  // 24 MFMAs: smallest terms first; consecutive MFMAs go to different accumulators
-  auto matrix = [&](auto NT0, const Frags& f) {
-    constexpr int nt0 = decltype(NT0)::value;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) U[mt][nt0 + q] = mma_f16(f.vh[mt][0], f.wl[q][0], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) U[mt][nt0 + q] = mma_f16(f.vl[mt][0], f.wh[q][0], U[mt][nt0 + q]);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) U[mt][nt0 + q] = mma_f16(f.vh[mt][1], f.wl[q][1], U[mt][nt0 + q]);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) U[mt][nt0 + q] = mma_f16(f.vl[mt][1], f.wh[q][1], U[mt][nt0 + q]);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) U[mt][nt0 + q] = mma_f16(f.vh[mt][0], f.wh[q][0], U[mt][nt0 + q]);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) U[mt][nt0 + q] = mma_f16(f.vh[mt][1], f.wh[q][1], U[mt][nt0 + q]);
-  };
-  // out[l] += p[l][j] U[j] for the two feature fragments nt0, nt0 + 1 (weights of the head in `pr`)
-  auto combine = [&](auto NT0) {
-    constexpr int nt0 = decltype(NT0)::value;
-    // (the asm FMAs are invisible to hipcc's hazard recogniser: a matrix result may be read 11 states after its MFMA issued)
-    asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int j = 0; j < LK; ++j)   // (key outermost: an accumulator comes back 2 LQ instructions later, not 2)
-#pragma unroll
-        for (int l = 0; l < LQ; ++l)
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const int idx = l * 4 + j;
-            float& acc = out[mt][nt0 + q][l];
-            const float u = U[mt][nt0 + q][j];
-            switch (idx & 15) {   // (compile-time after unrolling)
-              case 0: fmac_bcast<0>(acc, pr[mt][idx >> 4], u); break;
-              case 1: fmac_bcast<1>(acc, pr[mt][idx >> 4], u); break;
-              case 2: fmac_bcast<2>(acc, pr[mt][idx >> 4], u); break;
-              case 4: fmac_bcast<4>(acc, pr[mt][idx >> 4], u); break;
-              case 5: fmac_bcast<5>(acc, pr[mt][idx >> 4], u); break;
-              case 6: fmac_bcast<6>(acc, pr[mt][idx >> 4], u); break;
-              case 8: fmac_bcast<8>(acc, pr[mt][idx >> 4], u); break;
-              case 9: fmac_bcast<9>(acc, pr[mt][idx >> 4], u); break;
-              case 10: fmac_bcast<10>(acc, pr[mt][idx >> 4], u); break;
-              case 12: fmac_bcast<12>(acc, pr[mt][idx >> 4], u); break;
-              case 13: fmac_bcast<13>(acc, pr[mt][idx >> 4], u); break;
-              default: fmac_bcast<14>(acc, pr[mt][idx >> 4], u); break;
-            }
-          }
-  };
-
-  const std::integral_constant<int, 0> N0{};
-  const std::integral_constant<int, 2> N2{};
-  // ---- prologue: heads 0 and 1 on their way; head 0 published ----
-  stage_head(0);
-  if (heads > 1) stage_head(1);
-  // (the wave's own outstanding pieces: counted per lane in issue order; a lane with a skipped value piece has fewer --
-  //  the count is the lane's own, the wait below is the conservative one: everything of head 0)
-  if (heads > 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  if (late == 1) __builtin_amdgcn_s_barrier();   // the late half: one phase behind from here on
-
-  for (int h = 0; h < heads; ++h) {
-    Frags f;
-    // ---- X_A(h) ----
-    read_frags(h, N0, f);
-    combine(N2);                                  // fragments 2, 3 of head h - 1 (weights still in pr)
-    if (h >= 1 && h + 1 < heads) stage_head(h + 1);   // into the slots of head h - 1
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    // ---- M_A(h) ----
-    matrix(N0, f);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    // ---- X_B(h) ----
-    read_frags(h, N2, f);
-    {
-      const char* pb = pbase + (h & 1) * PO_PTILE;
+    for (int nt = 0; nt < 4; ++nt) {
+      wh[nt] = *reinterpret_cast<const u32x4*>(buf + off_w[0] + nt * 16 * PO_ROWB);
+      wl[nt] = *reinterpret_cast<const u32x4*>(buf + off_w[1] + nt * 16 * PO_ROWB);
+    }
+    if constexpr (ks == 0) {   // this head's weights, for the combine that starts with the next head
+      const char* pb = pbase + ((st >> 1) & 1) * PO_PTILE;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int c = 0; c < PREGS; ++c) pr[mt][c] = *reinterpret_cast<const float*>(pb + off_p + mt * 4 * (PO_PS * 4) + c * 64);
+        for (int c = 0; c < PREGS; ++c) prn[mt][c] = *reinterpret_cast<const float*>(pb + off_p + mt * 4 * (PO_PS * 4) + c * 64);
     }
+    const int nx = st + 2 + late;
+    if (nx < n_st) stage_in(nx);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    combine(N0);                                   // fragments 0, 1 of head h
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of head h + 1 (issued two phases ago) have landed
+    // (the asm FMAs are invisible to hipcc's hazard recogniser -- a matrix result may be read 11 states after its MFMA issued --:
+    //  the products they read were finished at least a phase and a barrier ago)
+    unroll_idx(std::make_integer_sequence<int, 24>{}, [&](auto I) {
+      constexpr int i = decltype(I)::value, term = i / 8, mt = (i % 8) / 4, nt = i % 4;
+      const u32x4 a = term == 1 ? vl[mt] : vh[mt];
+      const u32x4 b = term == 0 ? wl[nt] : wh[nt];
+      if constexpr (ks == 0 && term == 0) Un[mt][nt] = mma_f16(a, b, f32x4{0.f, 0.f, 0.f, 0.f});
+      else Un[mt][nt] = mma_f16(a, b, Un[mt][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int e0 = i * NF / 24, e1 = (i + 1) * NF / 24;
+      unroll_idx(std::make_integer_sequence<int, e1 - e0>{}, [&](auto D) {
+        pair_one(U, pr, std::integral_constant<int, ks>{}, std::integral_constant<int, e0 + decltype(D)::value>{});
+      });
+      if constexpr (i == 23) base_add(U, std::integral_constant<int, ks>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (nx < n_st) {   // (uniform) leave the pieces of stage nx in flight: 5 with P, else 4
+      if ((nx & 1) == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
-    // ---- M_B(h) ----
-    matrix(N2, f);
-    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: stages 0, 1 on their way (the late half: 0, 1, 2); stage 0 published, then stage 1 by the late half ----
+  stage_in(0);
+  stage_in(1);
+  if (late == 1 && n_st > 2) stage_in(2);
+  if (late == 1 && n_st > 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // stages 1 (4 pieces) and 2 (5) in flight
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                          // stage 1 in flight
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (late == 1) {   // the late half: one phase behind from here on; its pieces of stage 1 land while the early half runs phase 0
+    if (n_st > 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
   }
-  combine(N2);   // fragments 2, 3 of the last head
+
+  const std::integral_constant<int, 0> K0{};
+  const std::integral_constant<int, 1> K1{};
+  // an even head combines (UA, prA) and multiplies into UB, its weights go to prB; an odd head the other way round
+  for (int h = 0; h < heads; h += 2) {
+    phase(2 * h, K0, UA, prA, UB, prB);
+    phase(2 * h + 1, K1, UA, prA, UB, prB);
+    phase(2 * h + 2, K0, UB, prB, UA, prA);
+    phase(2 * h + 3, K1, UB, prB, UA, prA);
+  }
+  // the last head's combine; then the level-independent part.  (Its products left the matrix pipe only just now, and the asm
+  // FMAs are invisible to hipcc's hazard recogniser: a late wave whose last barrier opens at once would read them early.)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  unroll_idx(std::make_integer_sequence<int, NF>{}, [&](auto E) { pair_one(UA, prA, K0, E); });
+  unroll_idx(std::make_integer_sequence<int, NF>{}, [&](auto E) { pair_one(UA, prA, K1, E); });
+  base_add(UA, K0);
+  base_add(UA, K1);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int l = 1; l < LQ; ++l) out[mt][nt][l] += out[mt][nt][0];
   if (late == 0) __builtin_amdgcn_s_barrier();   // (every wave passes the same number of barriers)
 
   // ---- result: undo the 2^6 weight scale (exact), bias; 16 bytes per (column, level): features n .. n + 3 ----
@@ -371,8 +373,11 @@ __global__ __launch_bounds__(256) void perceiver_probs_kernel(const PercProbArgs
     load4(kv0 + j * kv_step, kk[j]);
     load4(kv0 + j * kv_step + inner, vv[j]);
   }
-  // ---- the weights: every lane of the group ends up with all of them; lane i keeps those of query i ----
+  // ---- the weights: every lane of the group ends up with all of them; lane i keeps those of queries 2 i and 2 i + 1:
+  //      P[col][head][l][2] = (p0, p1) for level 0, their differences to level 0 for the others -- the third weight follows
+  //      from p0 + p1 + p2 = 1; how perceiver_out_kernel uses them is said there ----
   float mine[4] = {0.f, 0.f, 0.f, 0.f};
+  float p00 = 0.f, p10 = 0.f;
 #pragma unroll
   for (int c = 0; c < LQ; ++c) {
     float qv[4];
@@ -386,17 +391,16 @@ __global__ __launch_bounds__(256) void perceiver_probs_kernel(const PercProbArgs
 #pragma unroll
     for (int j = 0; j < LK; ++j) e[j] = __expf(sc[j] - m);
     const float inv = 1.0f / ((e[0] + e[1]) + e[2]);
-    if (i16 == c) {
-      mine[0] = e[0] * inv;
-      mine[1] = e[1] * inv;
-      mine[2] = e[2] * inv;
+    float w0 = e[0] * inv, w1 = e[1] * inv;
+    if (c == 0) { p00 = w0; p10 = w1; }
+    else { w0 -= p00; w1 -= p10; }
+    if (i16 == c / 2) {
+      mine[2 * (c & 1)] = w0;
+      mine[2 * (c & 1) + 1] = w1;
     }
   }
   float* prow = p.P + (col * p.heads + h) * PO_PS;
-  if (i16 * 4 < PO_PS) {
-    if (i16 >= LQ) mine[0] = mine[1] = mine[2] = 0.f;
-    store4(prow + i16 * 4, mine);
-  }
+  store4(prow + i16 * 4, mine);   // (lanes past the last query write zeros: the tile is defined everywhere)
   // ---- the values as fp16 pairs: lanes 2i, 2i + 1 hold 8 consecutive features between them and trade halves; the even
   //      lane stores the eight high halves, the odd one the remainders (the layout of aurora_hip_split_f16) ----
   const bool odd = (threadIdx.x & 1) != 0;
@@ -405,8 +409,11 @@ __global__ __launch_bounds__(256) void perceiver_probs_kernel(const PercProbArgs
 #pragma unroll
   for (int j = 0; j < LK; ++j) {
     uint32_t h0, h1, l0, l1;
-    split_pair_f16(vv[j][0], vv[j][1], h0, l0);
-    split_pair_f16(vv[j][2], vv[j][3], h1, l1);
+    // rows (v0 - v2, v1 - v2, v2): see perceiver_out_kernel
+    const float d0 = j < 2 ? vv[j][0] - vv[2][0] : vv[2][0], d1 = j < 2 ? vv[j][1] - vv[2][1] : vv[2][1];
+    const float d2 = j < 2 ? vv[j][2] - vv[2][2] : vv[2][2], d3 = j < 2 ? vv[j][3] - vv[2][3] : vv[2][3];
+    split_pair_f16(d0, d1, h0, l0);
+    split_pair_f16(d2, d3, h1, l1);
     const uint32_t s0 = swap1(odd ? h0 : l0), s1 = swap1(odd ? h1 : l1);
     char* d = p.Vp + ((col * LK + j) * inner + (f8 & ~31)) * 4 + (f8 & 31) * 2 + (odd ? 64 : 0);
     *reinterpret_cast<u32x4*>(d) = odd ? u32x4{s0, s1, l0, l1} : u32x4{h0, h1, s0, s1};
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256) void perceiver_probs_kernel(const PercProbArgs
 using namespace aurora;
 
 extern "C" int aurora_hip_perceiver_out_supported(int Lq, int Lk, int heads, int head_dim, int N) {
-  return (Lq == 3 || Lq == 4 || Lq == 13) && Lk == 3 && head_dim == 64 && heads >= 1 && N > 0 && N % PO_N == 0;
+  return (Lq == 3 || Lq == 4 || Lq == 13) && Lk == 3 && head_dim == 64 && heads >= 2 && heads % 2 == 0 && N > 0 && N % PO_N == 0;
 }
 
 extern "C" int aurora_hip_perceiver_probs(const float* q, const float* kv, float* P, void* Vp, int B, int64_t cols_per_b,

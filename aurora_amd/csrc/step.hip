@@ -59,7 +59,8 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     // writes there).  Two fp16 terms: decided on the device by the guard of the linear it replaces.
     const int64_t n_cols = (int64_t)B * cols;
     const bool att_pairs = ly.to_out_s != nullptr && inner % 32 == 0;
-    const bool reassoc = m.reassoc_out && i == 0 && att_pairs && att_in_y && Lk <= Lq && inner <= Dd && ly.f16_mode == 2 &&
+    const bool reassoc = m.reassoc_out && i == 0 && att_pairs && att_in_y && ly.f16_mode == 2 &&
+                         (size_t)n_cols * Lk * inner * 4 <= unit &&
                          aurora_hip_perceiver_out_supported(Lq, Lk, heads, ly.head_dim, Dd) != 0;
     const size_t p_off = (unit + 255) & ~size_t(255), p_bytes = reassoc ? (size_t)n_cols * heads * 64 * 4 : 0;
     const size_t s_bytes = std::max(std::max(att_in_y ? std::max(unit, kvq_bytes) : att_off + att_bytes, hid_min),

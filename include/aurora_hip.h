@@ -294,12 +294,13 @@ int aurora_hip_perceiver_attention_unless(const void* q, int64_t q_col_stride, c
  * the three values of a column are projected per head (Lk rows per column instead of Lq) and combined with the softmax
  * weights in registers; the attention output is never written.  fp32-grade: two fp16 terms per operand (the values must be
  * inside fp16's range: the caller's guard), fp32 weights p, fp32 accumulation.
- *   _probs: P[col][head][l][4] = softmax_j(q_l . k_j / 8) (fp32, 64 floats per (col, head), zero-padded) and
- *           Vp[col * 3 + j][inner] = v_j in the fp16-pair layout (AURORA_F32_A_SPLIT); q, kv as aurora_hip_perceiver_attention.
- *   _out:   out[col * Lq + l][0..N) = sum_h sum_j P[col][h][l][j] W_pairs[:, 64 h .. 64 h + 63] Vp[col * 3 + j][64 h ..] + bias;
+ *   _probs: P[col][head][l][2] = (p_0, p_1) of p = softmax_j(q_l . k_j / 8) for l = 0, their differences to level 0 for
+ *           l > 0 (fp32, 64 floats per (col, head), zero-padded; p_2 = 1 - p_0 - p_1) and Vp[col * 3 + j][inner] = (v_0 - v_2, v_1 - v_2, v_2)[j] in the fp16-pair layout
+ *           (AURORA_F32_A_SPLIT); q, kv as aurora_hip_perceiver_attention.
+ *   _out:   out[col * Lq + l][0..N) = sum_h W_h (Vp_2 + p_0 Vp_0 + p_1 Vp_1)[col, h] + bias, W_h = W_pairs[:, 64 h .. 64 h + 63];
  *           W_pairs: [N][ldw] pre-split weights scaled by 2^6 (aurora_hip_split_f16 with scale 64).
- * Both retire at once unless *guard < guard_limit (null: always run).  Built for Lq in {3, 4, 13}, Lk = 3, head_dim 64,
- * N % 128 == 0: aurora_hip_perceiver_out_supported says whether a shape is. */
+ * Both retire at once unless *guard < guard_limit (null: always run).  Built for Lq in {3, 4, 13},
+ * Lk = 3, head_dim 64, an even number of heads, N % 128 == 0: aurora_hip_perceiver_out_supported says whether a shape is. */
 int aurora_hip_perceiver_out_supported(int Lq, int Lk, int heads, int head_dim, int N);
 int aurora_hip_perceiver_probs(const float* q, const float* kv, float* P, void* Vp, int B, int64_t cols_per_b,
                                int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads, int head_dim,

@@ -739,15 +739,19 @@ def test_perceiver_out_reassociated_equals_attention_then_to_out(Lq, heads, N, c
     out = torch.full((B * cols * Lq, N), float("nan"), device=DEV)
     L.perceiver_out(Vp, w_pairs, P, out, B * cols, Lq, Lk, heads, hd)
     torch.cuda.synchronize()
-    # the weights: softmax over the three keys, [l][4] per (column, head), zero-padded
+    # the weights of keys 0 and 1 (the third follows from their sum), [l][2] per (column, head), zero-padded to 64 floats;
+    # level 0 as it is, the other levels as differences to level 0 (how perceiver_out combines them)
     kvr = kv.reshape(B, Lk, cols, 2, heads, hd)
     sc = torch.einsum("lhd,bjchd->bchlj", q.reshape(Lq, heads, hd), kvr[:, :, :, 0]) / 8.0
     p_ref = torch.softmax(sc, dim=-1).reshape(B * cols, heads, Lq, Lk)
-    p_got = P.reshape(B * cols, heads, 16, 4).cpu().double()
-    assert (p_got[:, :, :Lq, :Lk] - p_ref).abs().max().item() < 1e-6
-    assert p_got[:, :, Lq:].abs().max().item() == 0 and p_got[:, :, :, Lk:].abs().max().item() == 0
-    # the values as fp16 pairs: exactly what the splitting kernel makes of them, rows (col, j)
-    v = kvr[:, :, :, 1].permute(0, 2, 1, 3, 4).reshape(B * cols * Lk, inner).float().to(DEV)
+    p_got = P.reshape(B * cols, heads, 32, 2).cpu().double()
+    p_want = p_ref[..., :2].clone()
+    p_want[:, :, 1:] -= p_ref[:, :, :1, :2]   # (levels 1.. carry their difference to level 0)
+    assert (p_got[:, :, :Lq] - p_want).abs().max().item() < 1e-6
+    assert p_got[:, :, Lq:].abs().max().item() == 0
+    # the values as fp16 pairs of (v0 - v2, v1 - v2, v2): exactly what the splitting kernel makes of them, rows (col, j)
+    v = kvr[:, :, :, 1].permute(0, 2, 1, 3, 4).reshape(B * cols, Lk, inner).float().to(DEV)
+    v = torch.stack([v[:, 0] - v[:, 2], v[:, 1] - v[:, 2], v[:, 2]], dim=1).reshape(B * cols * Lk, inner)
     assert torch.equal(Vp, L.split_f16(v))
     assert relerr(out, ref) < 3e-6
 
