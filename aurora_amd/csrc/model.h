@@ -209,17 +209,16 @@ struct aurora_hip_model {
   void* stage_recv = nullptr;
   int64_t staging_bytes = 0, staging_need = 0;
   bool sharded() const { return band.world > 1; }
-  // process defaults read ONCE, when the handle is created (never inside a step): AURORA_FUSE_LN,
-  // AURORA_BAND_SPLIT_ATTENTION, AURORA_QKV_PLANES
+  // how this handle runs its steps: aurora_hip_config.tuning, fixed when the handle is created
   int fuse_ln = 1;
   bool split_attention = false;
   bool qkv_planes = true;   // bf16 blocks: q | k | v leave the qkv linear one attention head per plane (aurora_hip_linear_planes)
   bool reassoc_out = true;  // decoder de-aggregation: to_out of the three value rows per column, combined in registers (perceiver_out.hip)
+  bool kv_halo = true;      // sharded steps: neighbours exchange k | v of their boundary rows (step.hip)
 
   // per step
   aurora::DevBuf abs_enc, dyn_planes, ctx_max;
   aurora::DevBuf tickets;   // split-K tickets of aurora_hip_linear_ws: SPLIT_TICKETS zeroed words, left zero by every launch
-  bool tickets_suspect = false;   // the last step did not return normally: its launches may have left counts behind
   // AURORA_SPLIT_K=0 at creation: no linear is ever split along K, so that a band's bf16 arithmetic is the un-sharded step's
   // bit for bit and does not depend on the device's CU count (split-K is chosen from the tile count against the CUs)
   bool split_k = true;

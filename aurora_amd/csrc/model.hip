@@ -648,10 +648,19 @@ extern "C" int aurora_hip_create(const aurora_hip_config* c, aurora_hip_model** 
     build_blocks(*m);
     build_channels(*m);
     m->ctx_max = DevBuf(16);
-    if (const char* e = getenv("AURORA_FUSE_LN")) m->fuse_ln = atoi(e);
-    if (const char* e = getenv("AURORA_BAND_SPLIT_ATTENTION")) m->split_attention = atoi(e) != 0;
-    if (const char* e = getenv("AURORA_QKV_PLANES")) m->qkv_planes = atoi(e) != 0;
-    if (const char* e = getenv("AURORA_SPLIT_K")) m->split_k = atoi(e) != 0;
+    // how this handle runs its steps: fields of the configuration (0 = the library's default), never the environment
+    const auto& tu = c->tuning;
+    REQUIRE(tu.fuse_ln >= 0 && tu.fuse_ln <= 3, "create: tuning.fuse_ln = %d (0 default, 1 never, 2 by the fill rule, 3 always)", tu.fuse_ln);
+    auto sw = [](int32_t v, bool dflt, const char* what) {
+      REQUIRE(v >= 0 && v <= 2, "create: tuning.%s = %d (0 default, 1 off, 2 on)", what, v);
+      return v == 0 ? dflt : v == 2;
+    };
+    m->fuse_ln = tu.fuse_ln == 0 ? 1 : tu.fuse_ln - 1;
+    m->split_attention = sw(tu.band_split_attention, false, "band_split_attention");
+    m->qkv_planes = sw(tu.qkv_planes, true, "qkv_planes");
+    m->split_k = sw(tu.split_k, true, "split_k");
+    m->reassoc_out = sw(tu.perceiver_reassoc, true, "perceiver_reassoc");
+    m->kv_halo = sw(tu.kv_halo, true, "kv_halo");
     m->tickets = DevBuf(SPLIT_TICKETS * sizeof(int32_t));
     hip_ok(hipMemset(m->tickets.p, 0, SPLIT_TICKETS * sizeof(int32_t)), "hipMemset");
     *out = m.release();
@@ -1223,12 +1232,13 @@ extern "C" int aurora_hip_step(aurora_hip_model* mp, const aurora_hip_step_io* i
       m.arena.cap = m.arena.peak;
       m.generation += 1;
     }
-    // split-K tickets are trusted to be zero (gemm.hip): a step that did not return normally may have left counts behind
-    if (m.tickets_suspect)
-      hip_ok(hipMemsetAsync(m.tickets.p, 0, SPLIT_TICKETS * sizeof(int32_t), as_stream(stream)), "re-zeroing the split-K tickets");
-    m.tickets_suspect = true;
+    // split-K tickets must be zero when a launch starts (gemm.hip).  Every launch leaves them zero, but a launch that was
+    // aborted on the DEVICE (a fault, a reset) returns normally to the host and may have left counts behind: a sharded step --
+    // the only kind that splits along K -- clears them first, whatever happened before (one 16 KiB memset node; a captured
+    // graph replays it too).
+    if (m.sharded() && m.split_k)
+      hip_ok(hipMemsetAsync(m.tickets.p, 0, SPLIT_TICKETS * sizeof(int32_t), as_stream(stream)), "zeroing the split-K tickets");
     run_step(m, s, stream);
-    m.tickets_suspect = false;
   })
 }
 

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const LnArgs p) {
   const T* yr = reinterpret_cast<const T*>(p.y) + row * p.ldy;
   const float* rr = nullptr;
   // (a 64-bit remainder is ~100 instructions of a software division: rows fit 32 bits in every launch of the step)
-  if (p.res) rr = p.res + (p.res_mod > 0 ? (int64_t)((p.M >> 32) == 0 ? (uint32_t)row % (uint32_t)p.res_mod : row % p.res_mod) : row) * p.ldr;
+  if (p.res) rr = p.res + (p.res_mod > 0 ? (int64_t)(((p.M | p.res_mod) >> 32) == 0 ? (uint32_t)row % (uint32_t)p.res_mod : row % p.res_mod) : row) * p.ldr;
   const bool res_plain = PRE && rr != nullptr && !p.split_res;   // (uniform)
   float v[NC][4], r4[PRE ? NC : 1][4];
   // Both operands of a row are requested before anything waits: with few rows per CU (a latitude band's coarse stages:

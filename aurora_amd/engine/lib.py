@@ -610,6 +610,26 @@ _PF = ctypes.POINTER(ctypes.c_float)
 _PS = ctypes.POINTER(ctypes.c_char_p)
 
 
+class HipTuning(ctypes.Structure):   # aurora_hip_config.tuning: 0 = the library's default
+    _fields_ = [("fuse_ln", c_int32), ("band_split_attention", c_int32), ("qkv_planes", c_int32), ("split_k", c_int32),
+                ("perceiver_reassoc", c_int32), ("kv_halo", c_int32), ("reserved", c_int32 * 2)]
+
+
+def tuning_from_env() -> HipTuning:
+    """The AURORA_* switches of INTEGRATION.md, read HERE (once per handle creation) and handed to the library as fields of
+    the configuration: the library itself never reads the environment."""
+    t = HipTuning()
+    e = os.environ.get
+    if e("AURORA_FUSE_LN") is not None:
+        t.fuse_ln = int(e("AURORA_FUSE_LN")) + 1            # 0 / 1 / 2 -> never / fill rule / always
+    for field, var in (("band_split_attention", "AURORA_BAND_SPLIT_ATTENTION"), ("qkv_planes", "AURORA_QKV_PLANES"),
+                       ("split_k", "AURORA_SPLIT_K"), ("perceiver_reassoc", "AURORA_PERCEIVER_REASSOC"),
+                       ("kv_halo", "AURORA_KV_HALO")):
+        if e(var) is not None:
+            setattr(t, field, 2 if int(e(var)) != 0 else 1)
+    return t
+
+
 class HipConfig(ctypes.Structure):   # aurora_hip_config, field for field
     _fields_ = [("embed_dim", c_int32), ("patch_size", c_int32), ("latent_levels", c_int32), ("num_heads", c_int32),
                 ("n_stages", c_int32), ("encoder_depths", c_int32 * 4), ("encoder_heads", c_int32 * 4),
@@ -630,7 +650,7 @@ class HipConfig(ctypes.Structure):   # aurora_hip_config, field for field
                 ("n_positive_atmos", c_int32), ("positive_atmos_vars", _PS),
                 ("n_surf_inputs", c_int32), ("surf_inputs", _PS),
                 ("n_density", c_int32), ("density_channel_surf_vars", _PS),
-                ("n_angle", c_int32), ("angle_surf_vars", _PS)]
+                ("n_angle", c_int32), ("angle_surf_vars", _PS), ("tuning", HipTuning)]
 
 
 class HipHaloMsg(ctypes.Structure):   # aurora_hip_halo_msg

@@ -223,6 +223,7 @@ class NativeModel:
             c.n_surf_inputs, c.surf_inputs = len(self.surf_inputs), keep["inputs"]
             c.n_density, c.density_channel_surf_vars = len(model.density_channel_surf_vars), keep["dens"]
             c.n_angle, c.angle_surf_vars = len(model.angle_surf_vars), keep["ang"]
+        c.tuning = lib.tuning_from_env()
         handle = ctypes.c_void_p()
         lib._check(L.aurora_hip_create(ctypes.byref(c), ctypes.byref(handle)))
         self._h = handle

@@ -98,9 +98,10 @@ int aurora_hip_linear_batched(const void* A, int64_t lda, const void* W, int64_t
  *   tickets, n_tickets         : int32 words, ZERO on entry and left zero (one per tile); fewer than tiles = no split.
  *                                NOT validated: a count left behind by a launch that never finished (a device fault, a
  *                                torn-down graph) means no workgroup of that tile ever draws its last ticket -- the tile's
- *                                output rows are never written, silently.  Re-zero the words (hipMemsetAsync) after
- *                                any failed launch; the model handle does so at the start of the step that follows a
- *                                failed one.  Two launches that may run at the same time need their own ticket words.
+ *                                output rows are never written, silently.  A device-side abort returns normally to the
+ *                                host, so "after a failed launch" cannot be told: re-zero the words (hipMemsetAsync) ahead
+ *                                of a batch of launches -- the model handle does so at the start of EVERY sharded step.
+ *                                Two launches that may run at the same time need their own ticket words.
  *   split                      : 0 lets the library choose, 1 forbids, > 1 asks for that many slices.
  * fp32 problems and shapes that would not split run exactly as aurora_hip_linear. */
 int64_t aurora_hip_linear_workspace(int64_t M, int N, int K, int dtype);
@@ -430,6 +431,21 @@ typedef struct aurora_hip_config {   /* Aurora.__init__ keywords, aurora/model/a
   int32_t n_surf_inputs;         const char* const* surf_inputs;              /* wave only; 0: = surf_vars */
   int32_t n_density;             const char* const* density_channel_surf_vars;
   int32_t n_angle;               const char* const* angle_surf_vars;
+  /* ---- how THIS handle runs its steps (results are the same bits or within the documented bounds either way); all zero =
+   * the library's defaults.  Read when the handle is created and kept in it: nothing reads the environment, and two handles
+   * of one process may differ.  (The Python front end fills these from the AURORA_* environment variables of INTEGRATION.md,
+   * once, when it creates a handle.)  Switches: 0 default, 1 off, 2 on. */
+  struct aurora_hip_tuning {
+    int32_t fuse_ln;               /* D = 512 linear + AdaLN in one launch: 0 default (= 2), 1 never, 2 when its row tiles fill the chip, 3 always */
+    int32_t band_split_attention;  /* a latitude band's interior windows as a launch of their own in front of the halo wait (default off) */
+    int32_t qkv_planes;            /* bf16 blocks: q | k | v in head planes (default on; off: token rows -- same bits) */
+    int32_t split_k;               /* few-tile / long-K bf16 linears split along K (default on; off: a band's bf16 arithmetic is the
+                                      un-sharded step's bit for bit whatever the CU count) */
+    int32_t perceiver_reassoc;     /* decoder de-aggregation re-associated (aurora_hip_perceiver_out; default on) */
+    int32_t kv_halo;               /* sharded steps: neighbours exchange k | v of their boundary rows instead of re-projecting each
+                                      other's input rows (default on) */
+    int32_t reserved[2];
+  } tuning;
 } aurora_hip_config;
 
 typedef struct aurora_hip_grid {     /* HOST pointers */
