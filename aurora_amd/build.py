@@ -16,8 +16,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "_lib" / "libaurora_hip.so"
-SOURCES = ("runtime.hip", "gemm.hip", "attention.hip", "norm.hip", "embed.hip", "perceiver_out.hip", "band.hip", "model.hip",
-           "step.hip")
+SOURCES = ("runtime.hip", "gemm.hip", "gemm_a4.hip", "attention.hip", "norm.hip", "embed.hip", "perceiver_out.hip", "band.hip",
+           "model.hip", "step.hip")
 ARCH = "gfx950"
 
 
@@ -32,7 +32,8 @@ def is_stale() -> bool:
     if not LIB.exists():
         return True
     built = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "band.h", CSRC / "model.h", PKG.parent / "include" / "aurora_hip.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "band.h", CSRC / "model.h", CSRC / "gemm_a4_loop.inc",
+                                          PKG.parent / "include" / "aurora_hip.h"]
     return any(d.stat().st_mtime > built for d in deps)
 
 
@@ -47,8 +48,9 @@ def build_library(force: bool = False, verbose: bool = True) -> Path:
         obj = LIB.parent / (src.replace(".hip", ".o"))
         # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in arch VGPRs (gfx950 has one unified file);
         # otherwise the softmax in the attention kernel pays a v_accvgpr_read per score.
+        # (AURORA_BUILD_FLAGS: extra compiler flags of a probe build, e.g. -DA4_EXPERIMENTS for tools/gemm_a4_stamps.py)
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-mllvm",
-               "-amdgpu-mfma-vgpr-form=1", "-c", str(CSRC / src), "-o", str(obj)]
+               "-amdgpu-mfma-vgpr-form=1", *os.environ.get("AURORA_BUILD_FLAGS", "").split(), "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

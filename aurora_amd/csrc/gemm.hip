@@ -48,6 +48,7 @@ constexpr int ROW_BYTES = 128;  // bytes of K per tile row
 constexpr int TILE_BYTES = 128 * ROW_BYTES;  // 16 KiB per operand per buffer
 constexpr int THREADS = 256;
 constexpr int ACT_GELU_FAST = 4;  // internal: fp32 results of the operand-splitting kernels, erf to 1.5e-7 (packed)
+constexpr int A4_DEFAULT_MIN_K = 0;   // (0: the four-wave kernel of gemm_a4.hip is off unless AURORA_GEMM_A4_MIN_K says otherwise)
 
 struct LinearArgs {
   const char* A; int64_t lda_b;   // byte strides
@@ -1705,6 +1706,13 @@ __global__ __launch_bounds__(FTHREADS, 2) void linear_ln512_kernel(const LinearL
 
 }  // namespace aurora
 
+// (gemm_a4.hip includes this file for the device code above -- LinearArgs, the LDS images, the epilogues -- and stops here)
+#ifndef AURORA_GEMM_DEVICE_ONLY
+
+// the four-wave tile with the hand-scheduled main loop (gemm_a4.hip, its own translation unit)
+extern "C" __attribute__((visibility("hidden"))) int aurora_a4_launch(const void* linear_args, unsigned n_blocks, unsigned batch,
+                                                                     void* stream);
+
 using namespace aurora;
 
 namespace {
@@ -1720,6 +1728,20 @@ int default_f32_mode() {
 }  // namespace
 
 extern "C" int aurora_hip_default_f32_gemm(void) { return default_f32_mode(); }
+
+namespace {
+// Smallest K (elements) of a plain bf16 linear on 256 x 256 tiles that takes the four-wave kernel with the hand-scheduled
+// main loop (gemm_a4.hip) instead of the eight-wave ping-pong one.  A read-once process default like AURORA_F32_GEMM
+// (AURORA_GEMM_A4_MIN_K; 0 = never): both kernels accumulate K in the same 32-wide steps -- the same bits either way.
+int a4_min_k() {
+  static const int v = [] {
+    const char* e = getenv("AURORA_GEMM_A4_MIN_K");
+    const int k = e ? atoi(e) : A4_DEFAULT_MIN_K;
+    return k <= 0 ? 0x7fffffff : k;
+  }();
+  return v;
+}
+}  // namespace
 
 namespace {
 // Scratch of a split-K launch, owned by the caller: fp32 slabs (split x 256 KiB per tile; contents do not matter) and one
@@ -1957,6 +1979,8 @@ int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const fl
       hipLaunchKernelGGL((linear_kernel_256<float, 4, 4>), grid, dim3(THREADS2), NSTAGE2 * STAGE2, as_stream(stream), p);
     else if (ksplit > 1)       // ping-pong main loop, one workgroup per K-slice of a tile
       hipLaunchKernelGGL(linear_kernel_256pp<true>, dim3((unsigned)(p.n_blocks * ksplit)), dim3(THREADS2), PP_LDS, as_stream(stream), p);
+    else if (p.k_tiles >= 8 && p.k_tiles % 2 == 0 && K >= a4_min_k())
+      (void)aurora_a4_launch(&p, (unsigned)p.n_blocks, (unsigned)batch, stream);   // four waves, hand-scheduled loop (gemm_a4.hip)
     else if (p.k_tiles >= 4)   // ping-pong main loop, one workgroup per tile
       hipLaunchKernelGGL(linear_kernel_256pp<false>, grid, dim3(THREADS2), PP_LDS, as_stream(stream), p);
     else
@@ -2016,3 +2040,5 @@ extern "C" int aurora_hip_linear_layernorm(const void* A, int64_t lda, const voi
   }
   return check_launch("linear_layernorm");
 }
+
+#endif  // AURORA_GEMM_DEVICE_ONLY

@@ -696,6 +696,7 @@ PROFILE_KINDS = ("linear_bf16", "linear_f32", "window_attention_bf16", "layernor
                  "gather_rows", "perceiver_out")
 
 _SIGNATURES.update({
+    "aurora_hip_debug_a4_stamps": (None, [c_void_p]),
     "aurora_hip_profile_begin": (c_int, [c_void_p, ctypes.c_uint32]),
     "aurora_hip_profile_end": (c_int, [c_void_p, ctypes.POINTER(HipProfileEntry), c_int, ctypes.POINTER(c_int)]),
     "aurora_hip_profile_end_list": (c_int, [c_void_p, ctypes.POINTER(HipProfileEntry), c_int, ctypes.POINTER(c_int)]),

@@ -614,6 +614,12 @@ int aurora_hip_profile_end(aurora_hip_model* model, aurora_hip_profile_entry* ou
  * smaller than the number of recorded launches only *n_out is set and the recording is kept: query first, then fetch. */
 int aurora_hip_profile_end_list(aurora_hip_model* model, aurora_hip_profile_entry* out, int capacity, int* n_out);
 
+/* ---- debugging aid ------------------------------------------------------------------------------
+ * The four-wave bf16 GEMM tile with the hand-scheduled main loop (csrc/gemm_a4.hip; plain bf16 linears on 256 x 256 tiles with
+ * K >= AURORA_GEMM_A4_MIN_K, a read-once process default) can leave s_memtime stamps of workgroups 0 and 255 in 8 x 8 device
+ * words -- per wave: kernel start, loop start, loop end, 64-wide K units, kernel end -- for tools/gemm_a4_stamps.py.  NULL switches it off. */
+void aurora_hip_debug_a4_stamps(void* device_words);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,6 +125,24 @@ def test_attention_layouts_give_the_same_prediction_bit_for_bit(monkeypatch):
         assert all(torch.equal(outs[("0", fuse)][k], v) for k, v in outs[("1", fuse)].items()), fuse
 
 
+def test_decoder_reassociation_equals_attention_then_to_out_at_model_level(monkeypatch):
+    """The decoder's level de-aggregation re-associated (csrc/perceiver_out.hip: to_out of a column's three value rows, the
+    13 x 48 combinations in registers) against the plain pair it replaces (perceiver attention, then the 13-row `to_out`) in
+    the same fp32 model at the production widths: the same function, summed in another order -- fp32 round-off apart.  (Both
+    are compared with the oracle by the tests above / below; this one isolates the re-association.)"""
+    outs = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("AURORA_PERCEIVER_REASSOC", on)
+        model = _seeded_model(aurora_amd.AuroraPretrained, autocast=False)
+        batch = _inputs(model.config, 181, 360, LEVELS13)
+        outs[on] = _engine(model, batch)
+        del model
+        torch.cuda.empty_cache()
+    worst = max(helpers.mean_rel_err(outs["1"][k], outs["0"][k]) for k in outs["0"])
+    print(f"re-associated vs plain decoder de-aggregation: worst mean-rel {worst:.3e}")
+    assert 0 < worst < 2e-6   # (not the same launches -- and not further apart than fp32 summation orders are)
+
+
 def test_pretrained_quarter_grid_matches_oracle():
     """AuroraPretrained() on 361 x 720 = a quarter of the 0.25-degree tokens (token grid (4, 90, 180); stages (45, 90) and
     (23, 45) padded): M = 64,800 / 16,200 / 4,140 rows per stage, so the M-dependent dispatch of the headline step is
