@@ -8,8 +8,8 @@
 // i.e. project the 3 values of a column per head once (194,400 rows instead of 842,400: 0.41 instead of 1.77 TFLOP
 // fp32-equivalent) and take the 13 x 48 convex combinations per column in registers.  Two kernels:
 //
-//   perceiver_probs_kernel   per (column, head): the 13 x 3 softmax weights p (fp32) -> P[col][head][l][j (4)], and the
-//                            column's value rows re-written in the fp16-pair layout of the two-term GEMMs (gemm.hip,
+//   perceiver_probs_kernel   per (column, head): the 13 x 3 softmax weights p (fp32) -> P[col][head] (16 pairs, see there), and
+//                            the column's value rows re-written in the fp16-pair layout of the two-term GEMMs (gemm.hip,
 //                            "The fp16-pair layout") -> Vp[col * 3 + j][inner].  HBM-bound: reads k | v once.
 //   perceiver_out_kernel     U_h = Vp_h . W_out_h^T on the matrix pipe (two fp16 terms, three MFMAs per product, weights
 //                            pre-split and scaled by 2^6 as everywhere), out[l] += p[l,h,j] U_h[j] on the VALU, 16 heads,
@@ -18,18 +18,20 @@
 // perceiver_out_kernel, per workgroup: 32 columns (128 operand rows: row 4 c + j, j = 3 unused) x 128 output features;
 // 8 waves as 4 (column groups of 8) x 2 (64 features).  The MFMA "A" operand is the VALUE tile, so lane (g = lane >> 4,
 // i = lane & 15) of a 16 x 16 result holds rows 4 g .. 4 g + 3 = the three keys of ONE column for feature i: the combine
-// needs no cross-lane traffic for U.  The weights p of that column arrive through LDS one value per lane and are
-// broadcast inside the 16-lane row by DPP (v_fmac_f32_dpp ... row_newbcast): 39 FMAs per U tile, no moves.
+// needs no cross-lane traffic for U.  The weights p of that column arrive through LDS one PAIR (two levels, one key) per
+// lane and are broadcast inside the 16-lane row by a 64-bit DPP move; the FMAs are packed (two levels per instruction).
 // Weight rows are interleaved (LDS row 16 nt + i <-> feature 4 i + nt) so that a lane ends up with 4 CONSECUTIVE features
 // per (column, level): the result leaves as 16-byte stores covering 256 contiguous bytes per column and level.
 // K runs over the heads: a head is two K-stages of 32 (128 bytes per operand row in the pair layout), staged by LDS-DMA
 // into a ring of four stages (two heads) + the head's 8 KiB tile of P, all by counted waits.
-// Schedule (ping-pong, as linear_kernel_f32pp): per head four phases  X_A  M_A  X_B  M_B  with a barrier after each;
-//   M_A / M_B: 24 MFMAs each -- the products of feature fragments 0, 1 / 2, 3 --, nothing else;
-//   X_A: fragment reads for M_A, combine of the PREVIOUS head's fragments 2, 3, LDS-DMA of the next head;
-//   X_B: fragment reads for M_B, this head's P, combine of fragments 0, 1, wait for the next head's pieces.
-// Waves 4-7 run one phase behind waves 0-3 (their SIMD partners): a SIMD's matrix pipe belongs to one wave while the
-// other does the LDS / VALU work.
+// Schedule: per K-stage two slots with a barrier after each --
+//   R: the stage's 12 fragment reads (+ the head's weights), the LDS-DMA of stage st + 3, the counted wait;
+//   C: 24 MFMAs, the previous head's combine for one row fragment dealt out between them;
+// waves 4-7 run one slot behind waves 0-3 (their SIMD partners): one computes while the other reads.
+// What bounds it (tools/probes/mfma_valu_mix.py, mfma_valu_overlap.hip, profiles/r06_perceiver_out_dev.log): an MFMA holds
+// the SIMD's VALU issue port for 8 of its 16 cycles, whichever wave the next VALU instruction comes from, so per SIMD and
+// K-stage 48 MFMAs x 8 + 2 x 70 combine instructions x ~5.9 ~ 1,200 cycles are the floor of this formulation (the matrix pipe
+// alone: 768); the schedule above runs at ~1,700.
 #include <type_traits>
 #include <utility>
 
@@ -50,6 +52,10 @@ constexpr int PO_PS = 64;                   // floats of P per (column, head): [
 constexpr int PO_PTILE = PO_COLS * PO_PS * 4;   // 8 KiB: the 32 columns' weights of one head
 constexpr int PO_LDS = PO_NST * PO_STAGE + 2 * PO_PTILE;   // 144 KiB
 
+#ifdef PO_STAMPS   // probe build (AURORA_BUILD_FLAGS=-DPO_STAMPS): tools/probes/po_stamps.py
+__device__ uint32_t po_stamps[8 * 256];
+#endif
+
 struct PercOutArgs {
   const char* V; int64_t ldv_b;     // value rows in the fp16-pair layout: row col * 3 + j
   const char* W; int64_t ldw_b;     // weights [N][inner] in the fp16-pair layout, scaled by 2^6
@@ -64,13 +70,39 @@ __device__ __forceinline__ f32x4 mma_f16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
 }
 
-// a[nt] += p[lane K of this lane's row of 16] * u[nt], nt = 0..3: one broadcast (v_mov_b32_dpp row_newbcast -- cross-lane VALU
-// operations run at half rate, so the weight is broadcast once, not folded into each FMA) and four plain FMAs.  One asm
-// statement: hipcc would pad a state between dependent statements, and packs adjacent C++ FMAs into v_pk_fma_f32 pairs.
-// `w` is the caller's ONE scratch register, read-write in every statement and so live from the first to the last of them:
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The combine runs on PACKED fp32 FMAs (v_pk_fma_f32: two FMAs per lane and instruction at the rate of one plain FMA -- the
+// VALU, not the matrix pipe, bounds this kernel: 2 x 13 x 4 FMAs per product tile against three MFMAs), two LEVELS per
+// instruction:  (a[nt].lo, a[nt].hi) += u[nt][J] * (w.lo, w.hi), nt = 0..3, where (w.lo, w.hi) = the weights of levels 2 lp and
+// 2 lp + 1 for key J, held as a pair by lane K of this lane's row of 16 and broadcast by ONE 64-bit DPP move (row_newbcast is
+// the one DPP control 64-bit operands support; cross-lane VALU operations run at half rate, so the weights are broadcast
+// once, not folded into each FMA).  `u` is the (key 0, key 1) half of a product tile's four registers, op_sel picks key J
+// for both halves.  One asm statement: hipcc would pad a state between dependent statements.
+// `w` is the caller's ONE scratch pair, read-write in every statement and so live from the first to the last of them:
 // as a per-statement output hipcc put it into the dead fourth element of whatever product tile the MFMA in front had just
 // been issued into -- the matrix pipe then overwrote the weight between two FMAs (the hazard recogniser does not look
 // into asm statements).  A value that is live across an MFMA cannot share a register with its result.
+template <int K, int J>
+__device__ __forceinline__ void pkfma4_bcast(f32x2& a0, f32x2& a1, f32x2& a2, f32x2& a3, f32x2& w, f32x2 p, f32x2 u0, f32x2 u1,
+                                             f32x2 u2, f32x2 u3) {
+  if constexpr (J == 0)
+    asm volatile("v_mov_b64_dpp %4, %5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_pk_fma_f32 %0, %6, %4, %0 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %7, %4, %1 op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %2, %8, %4, %2 op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %3, %9, %4, %3 op_sel_hi:[0,1,1]"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w)
+                 : "v"(p), "v"(u0), "v"(u1), "v"(u2), "v"(u3), "i"(K));
+  else
+    asm volatile("v_mov_b64_dpp %4, %5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_pk_fma_f32 %0, %6, %4, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %1, %7, %4, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %2, %8, %4, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %3, %9, %4, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(w)
+                 : "v"(p), "v"(u0), "v"(u1), "v"(u2), "v"(u3), "i"(K));
+}
+
+// the odd last level: a[nt] += p[lane K of the row] * u[nt], one 32-bit broadcast and four plain FMAs
 template <int K>
 __device__ __forceinline__ void fma4_bcast(float& a0, float& a1, float& a2, float& a3, float& w, float p, float u0, float u1,
                                            float u2, float u3) {
@@ -96,7 +128,9 @@ template <int LQ>
 __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const PercOutArgs p) {
   static_assert(LQ >= 1 && LQ * 4 <= PO_PS, "level queries per column");
   constexpr int LK = 3;
-  constexpr int PREGS = (LQ * 2 + 15) / 16;   // P of a (column, head): [l][2] = the weights of keys 0 and 1
+  // P of a (column, head): 2 NLP pairs -- pair j * NLP + lp = the weights of levels 2 lp, 2 lp + 1 for key j (j = 0, 1)
+  constexpr int NLP = (LQ + 1) / 2, NFULL = LQ / 2;
+  static_assert(2 * NLP <= 16, "one pair of weights per lane of a row of 16");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (p.guard != nullptr && !(*p.guard < p.guard_limit)) return;   // (uniform)
   const int tid = threadIdx.x;
@@ -162,26 +196,29 @@ __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const Perc
     off_w[t] = PO_OPER + (wn * 64 + i16) * PO_ROWB + (((g + 4 * t) ^ (i16 & 7)) << 4);
   }
   // this lane's share of its columns' weights: value 16 c + i16 of column wm * 8 + 4 mt + g
-  const int off_p = (wm * 8 + g) * (PO_PS * 4) + i16 * 4;
+  const int off_p = (wm * 8 + g) * (PO_PS * 4) + i16 * 8;
 
-  float out[2][4][LQ];
+  // accumulators: levels in pairs (the operands of the packed FMAs), an odd last level on its own
+  f32x2 out2[2][4][NFULL > 0 ? NFULL : 1];
+  float outl[2][4];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
-      for (int l = 0; l < LQ; ++l) out[mt][nt][l] = 0.f;
+      for (int l = 0; l < NFULL; ++l) out2[mt][nt][l] = f32x2{0.f, 0.f};
+      outl[mt][nt] = 0.f;
+    }
   // Two sets of products and weights, A and B: an even head combines A (the previous head's) while it multiplies into B, an
   // odd head the other way round (no moves; heads is even).  Head 0 combines zeros times zeros -- a branch around it would
   // make hipcc keep two copies of the 104 accumulators and move them every iteration.
   f32x4 UA[2][4], UB[2][4];
-  float prA[2][PREGS], prB[2][PREGS];
+  f32x2 prA[2], prB[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) UA[mt][nt] = UB[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < PREGS; ++c) prA[mt][c] = prB[mt][c] = 0.f;
+    prA[mt] = prB[mt] = f32x2{0.f, 0.f};
   }
 
   // The value rows of a column arrive as (v0 - v2, v1 - v2, v2) and the weights as (p0, p1) for level 0, (p0 - p0[0], p1 - p1[0])
@@ -189,37 +226,57 @@ __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const Perc
   //     sum_j p_j U_j  =  U'_2 + p0 U'_0 + p1 U'_1     (U' the products of those rows)
   // -- two FMAs per level instead of three --, level 0 collects the U'_2 of all heads, and the other levels accumulate their
   // DIFFERENCE to level 0, added at the end: no separate accumulator for the level-independent part.
-  float wtmp = 0.f;   // the broadcast weight of fma4_bcast
-  // One (level, key) pair of the combine of row fragment MT: element e of 2 LQ, key outermost (an accumulator comes back
-  // LQ pairs later): one broadcast of the weight, four FMAs.
-  auto pair_one = [&](f32x4 (&U)[2][4], float (&pr)[2][PREGS], auto MT, auto E) {
+  f32x2 wtmp = {0.f, 0.f};   // the broadcast weights of pkfma4_bcast
+  float wtmp1 = 0.f;         // ... of fma4_bcast
+  // One step of the combine of row fragment MT: element e of 2 NLP = (key j, level pair lp), key outermost (an accumulator
+  // comes back NLP steps later): one broadcast of the pair of weights, four packed FMAs.
+  auto lo2 = [](f32x4 u) { return __builtin_shufflevector(u, u, 0, 1); };
+  auto pair_one = [&](f32x4 (&U)[2][4], f32x2 (&pr)[2], auto MT, auto E) {
     constexpr int mt = decltype(MT)::value, e = decltype(E)::value;
-    constexpr int j = e / LQ, l = e % LQ, idx = l * 2 + j;
-    fma4_bcast<idx & 15>(out[mt][0][l], out[mt][1][l], out[mt][2][l], out[mt][3][l], wtmp, pr[mt][idx >> 4], U[mt][0][j],
-                         U[mt][1][j], U[mt][2][j], U[mt][3][j]);
+    constexpr int j = e / NLP, lp = e % NLP;
+    if constexpr (lp < NFULL)
+      pkfma4_bcast<e, j>(out2[mt][0][lp], out2[mt][1][lp], out2[mt][2][lp], out2[mt][3][lp], wtmp, pr[mt], lo2(U[mt][0]),
+                         lo2(U[mt][1]), lo2(U[mt][2]), lo2(U[mt][3]));
+    else
+      fma4_bcast<e>(outl[mt][0], outl[mt][1], outl[mt][2], outl[mt][3], wtmp1, pr[mt].x, U[mt][0][j], U[mt][1][j], U[mt][2][j],
+                    U[mt][3][j]);
   };
   auto base_add = [&](f32x4 (&U)[2][4], auto MT) {
     constexpr int mt = decltype(MT)::value;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) out[mt][nt][0] += U[mt][nt][2];
+    for (int nt = 0; nt < 4; ++nt) {
+      if constexpr (NFULL > 0) out2[mt][nt][0].x += U[mt][nt][2];
+      else outl[mt][nt] += U[mt][nt][2];
+    }
   };
-  // One phase = one K-stage (32 of a head's 64) per wave: 12 fragment reads (+ the head's weights), the LDS-DMA of a later
-  // stage, then 24 MFMAs into Un with the 2 LQ (level, key) pairs of row fragment `ks` of U between them (one broadcast + four
-  // FMAs each: the matrix pipe works on an instruction for 16 cycles, the wave issues the FMAs meanwhile).  Smallest terms
-  // first; consecutive MFMAs go to different accumulators.  A barrier ends the phase; waves 4-7 run one phase behind
-  // waves 0-3, their SIMD partners.
-  // Ring (a wave's phase q runs at time q for the early half, q + 1 for the late one): stage st is read at times st / st + 1;
-  // the early half issues stage st + 2 in phase st, the late half stage st + 3 -- both at time st / st + 1 into slots whose
-  // last reader finished a barrier before --; at the end of a phase everything but the pieces just issued has landed, so a
-  // stage is complete a barrier before its first reader.  P of head h travels with stage 2 h.
-  // Measured (s_memtime stamps, 0.25 degree shape): a phase takes ~2,080 cycles -- reads + DMA issue 400-600 (early half) /
-  // ~1,000 (late half, beside its partner's computing), computing 810-890 (158 instructions: a wave issues one every ~5
-  // cycles), then the early half waits ~600 at the barrier.  A schedule of two half-phases per stage (reads + 8 MFMAs |
-  // 16 MFMAs + DMA) measured 5 % slower.
-  constexpr int NF = 2 * LQ;   // (level, key) pairs per row fragment
+  // One K-stage (32 of a head's 64) per wave = two slots, R and C (the file header); a barrier ends each.
+  // Ring: the waves' slots are numbered s = 2 st (R) and 2 st + 1 (C) for the early half, one later for the late half.
+  // Stage st is read in slots 2 st (early) and 2 st + 1 (late); every wave issues its pieces of stage st + 3 in its R of
+  // stage st, into the ring slot of stage st - 1 (last read a barrier before), and ends that R waiting until only the pieces
+  // of stages st + 2 and st + 3 are in flight: stage st + 1 is complete, for every wave, a barrier before its first reader.
+  // P of head h travels with stage 2 h.
+  // Measured (s_memtime stamps, 0.25 degree shape, tools/probes/po_stamps.py on a -DPO_STAMPS build of round 6): R ~450-550
+  // cycles, C ~800-900 (24 MFMAs alone: ~400; the 70 VALU instructions alone: ~410 -- they add up, see the file header),
+  // ~100 per barrier.  Also measured and not kept: the combine in R instead of C (M = MFMAs only: +7 %), the combine's
+  // instructions dealt out singly between the MFMAs (+13 %), one slot per stage (+10 %).
+  constexpr int NF = 2 * NLP;   // (key, level pair) steps per row fragment
   const int n_st = 2 * heads;
-  auto phase = [&](int st, auto KS, f32x4 (&U)[2][4], float (&pr)[2][PREGS], f32x4 (&Un)[2][4], float (&prn)[2][PREGS]) {
+#ifdef PO_STAMPS
+  int sidx = 0;
+  auto stamp = [&]() {   // slot boundaries of workgroup 4000, per wave, through spare LDS
+    if (blockIdx.x == 4000) {
+      const uint64_t t = __builtin_amdgcn_s_memtime();
+      if (lane == 0) reinterpret_cast<uint32_t*>(smem + PO_LDS)[wave * 256 + sidx] = (uint32_t)t;
+    }
+    ++sidx;
+  };
+#else
+  auto stamp = [&]() {};
+#endif
+  auto phase = [&](int st, auto KS, f32x4 (&U)[2][4], f32x2 (&pr)[2], f32x4 (&Un)[2][4], f32x2 (&prn)[2]) {
     constexpr int ks = decltype(KS)::value;
+    stamp();
+    // ---- R: this stage's fragments (+ the head's weights), the LDS-DMA of stage st + 3; the SIMD partner computes meanwhile ----
     const char* buf = smem + (st & (PO_NST - 1)) * PO_STAGE;
     u32x4 vh[2], vl[2], wh[4], wl[4];
 #pragma unroll
@@ -235,16 +292,24 @@ __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const Perc
     if constexpr (ks == 0) {   // this head's weights, for the combine that starts with the next head
       const char* pb = pbase + ((st >> 1) & 1) * PO_PTILE;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int c = 0; c < PREGS; ++c) prn[mt][c] = *reinterpret_cast<const float*>(pb + off_p + mt * 4 * (PO_PS * 4) + c * 64);
+      for (int mt = 0; mt < 2; ++mt) prn[mt] = *reinterpret_cast<const f32x2*>(pb + off_p + mt * 4 * (PO_PS * 4));
     }
-    const int nx = st + 2 + late;
+    const int nx = st + 3;
     if (nx < n_st) stage_in(nx);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // stage st + 1 has landed when only the pieces of stages st + 2 (and st + 3) are in flight: 4 per stage, 5 with the
+    // head's P -- one of two consecutive stages is even
+    if (nx < n_st) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    else if (nx == n_st) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    stamp();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    stamp();
+    // ---- C: 24 MFMAs into Un, the steps of the previous head's combine between them; the partner reads ----
     // (the asm FMAs are invisible to hipcc's hazard recogniser -- a matrix result may be read 11 states after its MFMA issued --:
-    //  the products they read were finished at least a phase and a barrier ago)
+    //  the products they read were finished at least a stage and two barriers ago)
     unroll_idx(std::make_integer_sequence<int, 24>{}, [&](auto I) {
       constexpr int i = decltype(I)::value, term = i / 8, mt = (i % 8) / 4, nt = i % 4;
       const u32x4 a = term == 1 ? vl[mt] : vh[mt];
@@ -259,29 +324,20 @@ __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const Perc
       if constexpr (i == 23) base_add(U, std::integral_constant<int, ks>{});
       __builtin_amdgcn_sched_barrier(0);
     });
-    if (nx < n_st) {   // (uniform) leave the pieces of stage nx in flight: 5 with P, else 4
-      if ((nx & 1) == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    stamp();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
   };
 
-  // ---- prologue: stages 0, 1 on their way (the late half: 0, 1, 2); stage 0 published, then stage 1 by the late half ----
+  // ---- prologue: stages 0, 1, 2 on their way, stage 0 published; the late half starts one slot later ----
   stage_in(0);
   stage_in(1);
-  if (late == 1 && n_st > 2) stage_in(2);
-  if (late == 1 && n_st > 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // stages 1 (4 pieces) and 2 (5) in flight
-  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                          // stage 1 in flight
+  stage_in(2);
+  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // stages 1 (4 pieces) and 2 (5) in flight
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (late == 1) {   // the late half: one phase behind from here on; its pieces of stage 1 land while the early half runs phase 0
-    if (n_st > 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (late == 1) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
@@ -302,14 +358,15 @@ __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const Perc
   unroll_idx(std::make_integer_sequence<int, NF>{}, [&](auto E) { pair_one(UA, prA, K1, E); });
   base_add(UA, K0);
   base_add(UA, K1);
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int l = 1; l < LQ; ++l) out[mt][nt][l] += out[mt][nt][0];
+  auto level = [&](int mt, int nt, int l) -> float { return l < 2 * NFULL ? out2[mt][nt][l >> 1][l & 1] : outl[mt][nt]; };
   if (late == 0) __builtin_amdgcn_s_barrier();   // (every wave passes the same number of barriers)
 
+#ifdef PO_STAMPS
+  if (blockIdx.x == 4000) {
+    __syncthreads();
+    for (int i = tid; i < 8 * 256; i += PO_THREADS) po_stamps[i] = reinterpret_cast<uint32_t*>(smem + PO_LDS)[i];
+  }
+#endif
   // ---- result: undo the 2^6 weight scale (exact), bias; 16 bytes per (column, level): features n .. n + 3 ----
   const int n = n0 + wn * 64 + 4 * i16;
   f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -320,9 +377,11 @@ __global__ __launch_bounds__(PO_THREADS, 2) void perceiver_out_kernel(const Perc
     if (col >= p.n_cols) continue;
     float* row = p.out + col * LQ * p.ldo + n;
 #pragma unroll
-    for (int l = 0; l < LQ; ++l) {
-      const f32x4 v = {fmaf(out[mt][0][l], 0.015625f, b4.x), fmaf(out[mt][1][l], 0.015625f, b4.y),
-                       fmaf(out[mt][2][l], 0.015625f, b4.z), fmaf(out[mt][3][l], 0.015625f, b4.w)};
+    for (int l = 0; l < LQ; ++l) {   // level 0 holds the level-independent part, the others their difference to it
+      f32x4 v;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        v[nt] = fmaf(l == 0 ? level(mt, nt, 0) : level(mt, nt, l) + level(mt, nt, 0), 0.015625f, b4[nt]);
       *reinterpret_cast<f32x4*>(row + (int64_t)l * p.ldo) = v;
     }
   }
@@ -373,10 +432,11 @@ __global__ __launch_bounds__(256) void perceiver_probs_kernel(const PercProbArgs
     load4(kv0 + j * kv_step, kk[j]);
     load4(kv0 + j * kv_step + inner, vv[j]);
   }
-  // ---- the weights: every lane of the group ends up with all of them; lane i keeps those of queries 2 i and 2 i + 1:
-  //      P[col][head][l][2] = (p0, p1) for level 0, their differences to level 0 for the others -- the third weight follows
-  //      from p0 + p1 + p2 = 1; how perceiver_out_kernel uses them is said there ----
-  float mine[4] = {0.f, 0.f, 0.f, 0.f};
+  // ---- the weights: every lane of the group ends up with all of them; with w_j[l] = p_j of level 0, the DIFFERENCE to level 0
+  //      for the others (the third weight follows from p0 + p1 + p2 = 1; how perceiver_out_kernel uses them is said there),
+  //      P[col][head] = 16 pairs: pair j * NLP + lp = (w_j[2 lp], w_j[2 lp + 1]), j = 0, 1, NLP = ceil(Lq / 2); lane i keeps pair i ----
+  constexpr int NLP = (LQ + 1) / 2;
+  float mine[2] = {0.f, 0.f};
   float p00 = 0.f, p10 = 0.f;
 #pragma unroll
   for (int c = 0; c < LQ; ++c) {
@@ -394,13 +454,12 @@ __global__ __launch_bounds__(256) void perceiver_probs_kernel(const PercProbArgs
     float w0 = e[0] * inv, w1 = e[1] * inv;
     if (c == 0) { p00 = w0; p10 = w1; }
     else { w0 -= p00; w1 -= p10; }
-    if (i16 == c / 2) {
-      mine[2 * (c & 1)] = w0;
-      mine[2 * (c & 1) + 1] = w1;
-    }
+    if (i16 == c / 2) mine[c & 1] = w0;
+    if (i16 == NLP + c / 2) mine[c & 1] = w1;
   }
   float* prow = p.P + (col * p.heads + h) * PO_PS;
-  store4(prow + i16 * 4, mine);   // (lanes past the last query write zeros: the tile is defined everywhere)
+  // (lanes past the last pair write zeros: the 16 pairs perceiver_out_kernel's lanes read are defined everywhere)
+  *reinterpret_cast<float2*>(prow + i16 * 2) = make_float2(mine[0], mine[1]);
   // ---- the values as fp16 pairs: lanes 2i, 2i + 1 hold 8 consecutive features between them and trade halves; the even
   //      lane stores the eight high halves, the odd one the remainders (the layout of aurora_hip_split_f16) ----
   const bool odd = (threadIdx.x & 1) != 0;
@@ -425,6 +484,13 @@ __global__ __launch_bounds__(256) void perceiver_probs_kernel(const PercProbArgs
 }  // namespace aurora
 
 using namespace aurora;
+
+#ifdef PO_STAMPS
+extern "C" void aurora_hip_debug_po_stamps(void* dst) { (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(po_stamps), sizeof(po_stamps)); }
+constexpr int PO_LDS_LAUNCH = PO_LDS + 8192;
+#else
+constexpr int PO_LDS_LAUNCH = PO_LDS;
+#endif
 
 extern "C" int aurora_hip_perceiver_out_supported(int Lq, int Lk, int heads, int head_dim, int N) {
   return (Lq == 3 || Lq == 4 || Lq == 13) && Lk == 3 && head_dim == 64 && heads >= 2 && heads % 2 == 0 && N > 0 && N % PO_N == 0;
@@ -467,16 +533,16 @@ extern "C" int aurora_hip_perceiver_out(const void* Vp, const void* W_pairs, int
   static bool attr_done_dev[64] = {false};
   bool& attr_done = attr_done_dev[current_device() & 63];
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)perceiver_out_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PO_LDS);
-    (void)hipFuncSetAttribute((const void*)perceiver_out_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, PO_LDS);
-    (void)hipFuncSetAttribute((const void*)perceiver_out_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, PO_LDS);
+    (void)hipFuncSetAttribute((const void*)perceiver_out_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, PO_LDS_LAUNCH);
+    (void)hipFuncSetAttribute((const void*)perceiver_out_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, PO_LDS_LAUNCH);
+    (void)hipFuncSetAttribute((const void*)perceiver_out_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, PO_LDS_LAUNCH);
     attr_done = true;
   }
   const dim3 grid((unsigned)p.n_blocks), block(PO_THREADS);
   switch (Lq) {
-    case 3: hipLaunchKernelGGL(perceiver_out_kernel<3>, grid, block, PO_LDS, as_stream(stream), p); break;
-    case 4: hipLaunchKernelGGL(perceiver_out_kernel<4>, grid, block, PO_LDS, as_stream(stream), p); break;
-    default: hipLaunchKernelGGL(perceiver_out_kernel<13>, grid, block, PO_LDS, as_stream(stream), p); break;
+    case 3: hipLaunchKernelGGL(perceiver_out_kernel<3>, grid, block, PO_LDS_LAUNCH, as_stream(stream), p); break;
+    case 4: hipLaunchKernelGGL(perceiver_out_kernel<4>, grid, block, PO_LDS_LAUNCH, as_stream(stream), p); break;
+    default: hipLaunchKernelGGL(perceiver_out_kernel<13>, grid, block, PO_LDS_LAUNCH, as_stream(stream), p); break;
   }
   return check_launch("perceiver_out");
 }

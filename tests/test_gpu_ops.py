@@ -739,16 +739,22 @@ def test_perceiver_out_reassociated_equals_attention_then_to_out(Lq, heads, N, c
     out = torch.full((B * cols * Lq, N), float("nan"), device=DEV)
     L.perceiver_out(Vp, w_pairs, P, out, B * cols, Lq, Lk, heads, hd)
     torch.cuda.synchronize()
-    # the weights of keys 0 and 1 (the third follows from their sum), [l][2] per (column, head), zero-padded to 64 floats;
-    # level 0 as it is, the other levels as differences to level 0 (how perceiver_out combines them)
+    # the weights of keys 0 and 1 (the third follows from their sum) -- level 0 as it is, the other levels as differences to
+    # level 0 (how perceiver_out combines them) -- as 16 pairs per (column, head): pair j * NLP + lp = levels (2 lp, 2 lp + 1)
+    # of key j, NLP = ceil(Lq / 2): the operands of the packed FMAs; zeros behind the last level
     kvr = kv.reshape(B, Lk, cols, 2, heads, hd)
     sc = torch.einsum("lhd,bjchd->bchlj", q.reshape(Lq, heads, hd), kvr[:, :, :, 0]) / 8.0
     p_ref = torch.softmax(sc, dim=-1).reshape(B * cols, heads, Lq, Lk)
-    p_got = P.reshape(B * cols, heads, 32, 2).cpu().double()
-    p_want = p_ref[..., :2].clone()
-    p_want[:, :, 1:] -= p_ref[:, :, :1, :2]   # (levels 1.. carry their difference to level 0)
-    assert (p_got[:, :, :Lq] - p_want).abs().max().item() < 1e-6
-    assert p_got[:, :, Lq:].abs().max().item() == 0
+    p_got = P.reshape(B * cols, heads, 64)[:, :, :32].cpu().double()
+    nlp = (Lq + 1) // 2
+    p_want = torch.zeros(B * cols, heads, 2 * nlp, dtype=torch.float64)
+    p_want[:, :, :Lq] = p_ref[..., 0]
+    p_want[:, :, 1:Lq] -= p_ref[:, :, :1, 0]   # (levels 1.. carry their difference to level 0)
+    p_want = torch.cat([p_want, torch.zeros_like(p_want)], dim=2)
+    p_want[:, :, 2 * nlp:2 * nlp + Lq] = p_ref[..., 1]
+    p_want[:, :, 2 * nlp + 1:2 * nlp + Lq] -= p_ref[:, :, :1, 1]
+    assert (p_got[:, :, :4 * nlp] - p_want).abs().max().item() < 1e-6
+    assert p_got[:, :, 4 * nlp:].abs().max().item() == 0
     # the values as fp16 pairs of (v0 - v2, v1 - v2, v2): exactly what the splitting kernel makes of them, rows (col, j)
     v = kvr[:, :, :, 1].permute(0, 2, 1, 3, 4).reshape(B * cols, Lk, inner).float().to(DEV)
     v = torch.stack([v[:, 0] - v[:, 2], v[:, 1] - v[:, 2], v[:, 2]], dim=1).reshape(B * cols * Lk, inner)
