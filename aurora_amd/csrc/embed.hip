@@ -301,6 +301,86 @@ __global__ __launch_bounds__(256) void perceiver_attention_kernel(const PercArgs
   }
 }
 
+// The same attention from PRE-MULTIPLIED scores (first Perceiver layer: its queries are model constants, so
+//   q_l . (W_k x_j) = (W_k^T q_l) . x_j
+// and the key half of to_kv shrinks from `inner` columns to Lq * heads -- the rows W_k^T q_l / sqrt(head_dim) are made when the
+// weights are packed, model.hip:score_weights).  A context row of `vs` holds [v (inner) | ... scores at s_off: (query l, head h)
+// at l * heads + h].  Lane layout as above; a group's scores are the same address in all its lanes (one broadcast load), the
+// softmax needs no cross-lane traffic at all: two passes over a query's Lk scores (maximum, then exponentials), one over
+// the values.  QC queries share a pass over the column's values.
+struct PercScoreArgs {
+  const float* vs; int64_t ld; int s_off; void* out;
+  int B; int64_t cols_per_b, kv_bstride, kv_lstride; int Lq, Lk, heads;
+  const float* pair_guard; float pair_limit;
+  const float* skip_guard; float skip_limit;
+};
+
+template <int HDIM, int QC>
+__global__ __launch_bounds__(256) void perceiver_attention_scores_kernel(const PercScoreArgs p) {
+  constexpr int LPG = HDIM / 4;
+  if (p.skip_guard != nullptr && *p.skip_guard < p.skip_limit) return;   // (uniform)
+  const int inner = p.heads * HDIM;
+  const int64_t n_cols = (int64_t)p.B * p.cols_per_b;
+  const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPG;
+  const int d0 = (int)(threadIdx.x % LPG) * 4;
+  if (grp >= n_cols * p.heads) return;   // (whole groups leave together)
+  const int h = (int)(grp % p.heads);
+  const int64_t col = grp / p.heads;
+  const int b = (int)(col / p.cols_per_b);
+  const int64_t l = col - (int64_t)b * p.cols_per_b;
+  const bool pairs = p.pair_guard != nullptr && *p.pair_guard < p.pair_limit;   // (uniform)
+  const float* row0 = p.vs + (b * p.kv_bstride + l) * p.ld;
+  const int64_t step = p.kv_lstride * p.ld;
+  for (int i0 = 0; i0 < p.Lq; i0 += QC) {
+    const float* sc[QC];
+    float mx[QC], sum[QC], o[QC][4];
+#pragma unroll
+    for (int c = 0; c < QC; ++c) {
+      const int i = i0 + c < p.Lq ? i0 + c : p.Lq - 1;   // (a padded slot repeats the last query; not stored)
+      sc[c] = row0 + p.s_off + i * p.heads + h;
+      mx[c] = -INFINITY;
+      sum[c] = 0.f;
+      o[c][0] = o[c][1] = o[c][2] = o[c][3] = 0.f;
+    }
+#pragma unroll 4
+    for (int j = 0; j < p.Lk; ++j)
+#pragma unroll
+      for (int c = 0; c < QC; ++c) mx[c] = fmaxf(mx[c], sc[c][j * step]);
+#pragma unroll 4
+    for (int j = 0; j < p.Lk; ++j) {
+      float v4[4];
+      load4(row0 + j * step + h * HDIM + d0, v4);
+#pragma unroll
+      for (int c = 0; c < QC; ++c) {
+        const float e = __expf(sc[c][j * step] - mx[c]);
+        sum[c] += e;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[c][d] = fmaf(e, v4[d], o[c][d]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < QC; ++c) {
+      if (i0 + c < p.Lq) {
+        const float inv = 1.0f / sum[c];
+        const float r4[4] = {o[c][0] * inv, o[c][1] * inv, o[c][2] * inv, o[c][3] * inv};
+        if (pairs) {   // the fp16-pair layout, as perceiver_attention_kernel writes it
+          uint32_t h0, h1, l0, l1;
+          split_pair_f16(r4[0], r4[1], h0, l0);
+          split_pair_f16(r4[2], r4[3], h1, l1);
+          const bool odd = (threadIdx.x & 1) != 0;
+          auto swap1 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, true); };
+          const uint32_t s0 = swap1(odd ? h0 : l0), s1 = swap1(odd ? h1 : l1);
+          const int f8 = (h * HDIM + d0) & ~7;
+          char* d = reinterpret_cast<char*>(p.out) + ((col * p.Lq + i0 + c) * inner + (f8 & ~31)) * 4 + (f8 & 31) * 2 + (odd ? 64 : 0);
+          *reinterpret_cast<u32x4*>(d) = odd ? u32x4{s0, s1, l0, l1} : u32x4{h0, h1, s0, s1};
+        } else {
+          store4(reinterpret_cast<float*>(p.out) + (col * p.Lq + i0 + c) * inner + h * HDIM + d0, r4);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // assemble tokens
 // ------------------------------------------------------------------------------------------------
@@ -545,6 +625,37 @@ extern "C" int aurora_hip_perceiver_attention_unless(const void* q, int64_t q_co
   }
 #undef AURORA_PERC
   return check_launch("perceiver_attention");
+}
+
+extern "C" int aurora_hip_perceiver_attention_scores(const float* vs, int64_t ld_vs, int s_off, void* out, int B,
+                                                     int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk,
+                                                     int heads, int head_dim, const float* pair_guard, float pair_limit,
+                                                     const float* skip_guard, float skip_limit, void* stream) {
+  AURORA_CHECK_ARG(vs && out && Lq > 0 && Lk > 0 && heads > 0 && B > 0 && cols_per_b > 0, "perceiver_attention_scores: empty problem");
+  const int inner = heads * head_dim;
+  AURORA_CHECK_ARG(s_off >= inner && ld_vs >= (int64_t)s_off + (int64_t)Lq * heads && ld_vs % 4 == 0 && ((uintptr_t)vs % 16) == 0,
+                   "perceiver_attention_scores: a row is [v (heads * head_dim) | ... | scores (Lq * heads) at s_off], ld %% 4 == 0");
+  AURORA_CHECK_ARG(pair_guard == nullptr || (inner % 32 == 0 && head_dim % 8 == 0),
+                   "perceiver_attention_scores: fp16-pair output needs heads * head_dim %% 32 == 0");
+  PercScoreArgs p{vs, ld_vs, s_off, out, B, cols_per_b, kv_bstride, kv_lstride, Lq, Lk, heads, pair_guard, pair_limit, skip_guard,
+                  skip_limit};
+  const int64_t items = (int64_t)B * cols_per_b * heads * (head_dim / 4);
+  const dim3 grid(blocks_for(items, 256)), block(256);
+#define AURORA_PERC_S(HDIM)                                                                                                  \
+  do {                                                                                                                       \
+    if (Lq % 3 == 0 && Lq <= 6) hipLaunchKernelGGL((perceiver_attention_scores_kernel<HDIM, 3>), grid, block, 0, as_stream(stream), p); \
+    else if (Lq > 8) hipLaunchKernelGGL((perceiver_attention_scores_kernel<HDIM, 7>), grid, block, 0, as_stream(stream), p);    \
+    else hipLaunchKernelGGL((perceiver_attention_scores_kernel<HDIM, 4>), grid, block, 0, as_stream(stream), p);                \
+  } while (0)
+  switch (head_dim) {
+    case 16: AURORA_PERC_S(16); break;
+    case 32: AURORA_PERC_S(32); break;
+    case 64: AURORA_PERC_S(64); break;
+    case 128: AURORA_PERC_S(128); break;
+    default: AURORA_CHECK_ARG(false, "perceiver_attention_scores: head_dim %d not in {16,32,64,128}", head_dim);
+  }
+#undef AURORA_PERC_S
+  return check_launch("perceiver_attention_scores");
 }
 
 extern "C" int aurora_hip_assemble_tokens(const float* surf, const float* agg, const float* pos_scale,

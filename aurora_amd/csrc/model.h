@@ -94,7 +94,7 @@ struct Resampler {
   struct Layer {
     const float *to_q, *to_kv, *to_out, *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
     const float *ln_k_w = nullptr, *ln_k_b = nullptr, *ln_q_w = nullptr, *ln_q_b = nullptr;
-    int inner, head_dim, hidden, dim;
+    int inner, head_dim, hidden, dim, ctx_dim;
     float v_l1;
     int f16_mode;   // fp32 GEMM mode of this layer's bounded linears: 2 (two fp16 terms) when weights / LN bounds allow
     // the same weights in the fp16-pair layout, scaled by 2^6 (null where mode or shape rule it out): the two-term GEMMs
@@ -103,6 +103,11 @@ struct Resampler {
   };
   std::vector<Layer> layers;
   std::vector<DevBuf> own;
+  // First layer, queries known when the weights are packed (model.hip:score_weights): to_kv replaced by
+  //   [W_v (inner rows) | W_k^T q_l / sqrt(head_dim) per (query l, head h) (n_s = Lq * heads rows) | zero rows up to n_vs]
+  // -- a context row then carries its values and its SCORES with every query; the key projection does not exist.
+  DevBuf vs_w, vs_ws;      // fp32, and the fp16-pair layout scaled by 2^6 (empty: not eligible)
+  int n_s = 0, n_vs = 0, vs_lq = 0;
 };
 
 // One input channel of a patch embedding: where its pixels come from and how they are transformed (embed.hip patchify).
@@ -214,7 +219,7 @@ struct aurora_hip_model {
   bool split_attention = false;
   bool qkv_planes = true;   // bf16 blocks: q | k | v leave the qkv linear one attention head per plane (aurora_hip_linear_planes)
   bool reassoc_out = true;  // decoder de-aggregation: to_out of the three value rows per column, combined in registers (perceiver_out.hip)
-  bool kv_halo = true;      // sharded steps: neighbours exchange k | v of their boundary rows (step.hip)
+  bool score_weights = true;   // first Perceiver layers: scores from W_k^T q rows instead of a key projection (model.hip:score_weights)
 
   // per step
   aurora::DevBuf abs_enc, dyn_planes, ctx_max;

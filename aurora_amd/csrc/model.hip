@@ -229,6 +229,7 @@ Resampler pack_resampler(Model& m, const std::string& prefix, int depth, int hea
     l.head_dim = l.inner / heads;
     l.hidden = (int)m.T_(p + ".1.net.0.weight").shape[0];
     l.dim = (int)m.T_(p + ".0.to_out.weight").shape[0];
+    l.ctx_dim = (int)tkv.shape[1];
     // largest L1 row norm of the value projection: |v| <= v_l1 * max |context| (range guard of the fp16 operand split)
     const int64_t K = tkv.shape[1];
     std::vector<float> host((size_t)l.inner * K);
@@ -277,6 +278,61 @@ Resampler pack_resampler(Model& m, const std::string& prefix, int depth, int hea
 }
 
 
+
+// Scores without a key projection (first layer of a Perceiver: perceiver.py:141-152 with the queries of perceiver.py:224-226 /
+// decoder.py:225-231, which are model constants).  q_l . (W_k x) = (W_k^T q_l) . x, so `to_kv` becomes
+//   [ W_v  |  one row W_k,h^T q_l,h / sqrt(head_dim) per (query l, head h)  |  zero rows up to a multiple of 256 ]
+// -- Lq * heads rows instead of heads * head_dim: 48 instead of 512 in the encoder's level aggregation, 208 instead of 1,024 in
+// the decoder's de-aggregation -- and a context row leaves that linear with its values and its SCALED SCORES against every
+// query (embed.hip: perceiver_attention_scores_kernel; perceiver_out.hip: perceiver_probs_kernel<.., true>).  The rows are
+// summed in double on the host (64 terms each) and rounded once.  Not with a LayerNorm on the keys (`ln_k_q`), and only where
+// the pre-split form exists iff to_kv's does (a context in the fp16-pair layout needs pre-split weights, step.hip).
+void score_weights(Model& m, Resampler& r, const float* q0, int Lq, int heads) {
+  r.vs_w = DevBuf();
+  r.vs_ws = DevBuf();
+  r.n_s = r.n_vs = r.vs_lq = 0;
+  if (!m.score_weights || r.layers.empty() || q0 == nullptr) return;
+  const auto& l = r.layers[0];
+  if (l.ln_k_w != nullptr || l.head_dim * heads != l.inner || l.f16_mode < 0) return;
+  const int inner = l.inner, hd = l.head_dim, K = l.ctx_dim, n_s = Lq * heads;
+  const int n_vs = round_up(inner + n_s, 256);
+  if (n_vs >= 2 * inner) return;   // nothing saved
+  std::vector<float> wkv((size_t)2 * inner * K), q((size_t)Lq * inner), vs((size_t)n_vs * K, 0.f);
+  hip_ok(hipMemcpy(wkv.data(), l.to_kv, wkv.size() * 4, hipMemcpyDeviceToHost), "download");
+  hip_ok(hipMemcpy(q.data(), q0, q.size() * 4, hipMemcpyDeviceToHost), "download");
+  std::copy(wkv.begin() + (size_t)inner * K, wkv.end(), vs.begin());   // the value half: rows inner .. 2 inner of to_kv
+  const double scale = 1.0 / std::sqrt((double)hd);
+  std::vector<double> acc((size_t)K);
+  float s_max = 0.f;
+  for (int lq = 0; lq < Lq; ++lq)
+    for (int h = 0; h < heads; ++h) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      for (int d = 0; d < hd; ++d) {
+        const double qd = q[(size_t)lq * inner + h * hd + d];
+        const float* wr = wkv.data() + (size_t)(h * hd + d) * K;
+        for (int c = 0; c < K; ++c) acc[c] += qd * wr[c];
+      }
+      float* dst = vs.data() + (size_t)(inner + lq * heads + h) * K;
+      for (int c = 0; c < K; ++c) {
+        dst[c] = (float)(acc[c] * scale);
+        s_max = std::max(s_max, fabsf(dst[c]));
+      }
+    }
+  if (!(s_max < 1000.f)) return;   // (the two-term split scales weights by 2^6: the same bound as pack_resampler's)
+  DevBuf w(vs.size() * 4), ws;
+  hip_ok(hipMemcpy(w.p, vs.data(), vs.size() * 4, hipMemcpyHostToDevice), "upload");
+  if (l.to_kv_s != nullptr && l.f16_mode == 2 && K % 32 == 0 && K >= 96) {
+    ws = DevBuf(vs.size() * 4);
+    if (aurora_hip_split_f16(w.f(), K, ws.p, K, n_vs, K, 64.0f, nullptr) != AURORA_OK) throw std::runtime_error(aurora_hip_last_error());
+    hip_ok(hipDeviceSynchronize(), "split weights");
+  }
+  if ((l.to_kv_s != nullptr) != (ws.p != nullptr)) return;
+  r.vs_w = std::move(w);
+  r.vs_ws = std::move(ws);
+  r.n_s = n_s;
+  r.n_vs = n_vs;
+  r.vs_lq = Lq;
+}
 
 // What is known on the device about max |context| of a resampler: max|ctx| <= a * (*word) + c.  `pairs`: the context
 // buffer holds fp16 pairs iff *word < limit_kv (written so by a guarded two-term producer with that very guard), fp32 otherwise.
@@ -660,7 +716,7 @@ extern "C" int aurora_hip_create(const aurora_hip_config* c, aurora_hip_model** 
     m->qkv_planes = sw(tu.qkv_planes, true, "qkv_planes");
     m->split_k = sw(tu.split_k, true, "split_k");
     m->reassoc_out = sw(tu.perceiver_reassoc, true, "perceiver_reassoc");
-    m->kv_halo = sw(tu.kv_halo, true, "kv_halo");
+    m->score_weights = sw(tu.score_weights, true, "score_weights");
     m->tickets = DevBuf(SPLIT_TICKETS * sizeof(int32_t));
     hip_ok(hipMemset(m->tickets.p, 0, SPLIT_TICKETS * sizeof(int32_t)), "hipMemset");
     *out = m.release();
@@ -873,6 +929,8 @@ extern "C" int aurora_hip_finalize(aurora_hip_model* mp, void* stream) {
     if (l0.ln_q_w)
       L.layernorm(m.enc_q0.p, l0.inner, l0.ln_q_w, l0.ln_q_b, nullptr, 0, 0, m.enc_q0.f(), l0.inner, nullptr, 0, n_lat, l0.inner,
                   1e-5f, AURORA_F32);
+    hip_ok(hipStreamSynchronize(as_stream(stream)), "precompute sync");
+    score_weights(m, m.enc_rs, m.enc_q0.f(), n_lat, m.perceiver_heads);
     // ---- second decoder Perceiver for the variables of `separate_perceiver` (decoder.py:232-248) ----
     std::vector<std::string> sep = m.sep_perceiver;
     if (!m.mod_heads.empty())
@@ -1043,6 +1101,8 @@ extern "C" int aurora_hip_precompute(aurora_hip_model* mp, const aurora_hip_grid
       first_q(m.dec_rs, m.dec_q);
       if (m.has_alt) first_q(m.dec_rs_alt, m.dec_q_alt);
       hip_ok(hipStreamSynchronize(as_stream(stream)), "precompute sync");
+      score_weights(m, m.dec_rs, m.dec_q.f(), C, m.perceiver_heads);
+      if (m.has_alt) score_weights(m, m.dec_rs_alt, m.dec_q_alt.f(), C, m.perceiver_heads);
       // What a decoder Perceiver can put out, whatever the inputs: every layer returns LN2(.) + LN1(.) + its residual, the
       // first residual being the level queries -- |LN(x) g + b| <= sqrt(D) max|g| + max|b|.  Decides whether the output may
       // leave in the fp16-pair layout for the output heads' two-term GEMM (step.hip).

@@ -396,6 +396,7 @@ struct PercProbArgs {
   const float* q; const float* kv; float* P; char* Vp;
   int B; int64_t cols_per_b, kv_bstride, kv_lstride; int heads;
   const float* guard; float guard_limit;
+  int64_t ld; int s_off;   // SCORES: a context row is [v (inner) | ... | scores at s_off], ld floats apart (else k | v, 2 inner)
 };
 
 __device__ __forceinline__ float group16_sum(float v) {
@@ -409,7 +410,10 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
-template <int LQ>
+// SCORES: the scaled scores q_l . k_j arrive pre-multiplied in the context rows (embed.hip, perceiver_attention_scores_kernel:
+// the queries of a first layer are model constants); lane i of a group then owns level i -- its three scores are three
+// loads, its softmax needs no other lane.
+template <int LQ, bool SCORES>
 __global__ __launch_bounds__(256) void perceiver_probs_kernel(const PercProbArgs p) {
   constexpr int HDIM = 64, LK = 3;
   if (p.guard != nullptr && !(*p.guard < p.guard_limit)) return;   // (uniform)
@@ -424,42 +428,73 @@ __global__ __launch_bounds__(256) void perceiver_probs_kernel(const PercProbArgs
   const int b = (int)(col / p.cols_per_b);
   const int64_t l = col - (int64_t)b * p.cols_per_b;
   const float scale = 0.125f;   // 1 / sqrt(64)
-  const float* kv0 = p.kv + (b * p.kv_bstride + l) * (2 * (int64_t)inner) + h * HDIM + d0;
-  const int64_t kv_step = p.kv_lstride * (2 * (int64_t)inner);
-  float kk[LK][4], vv[LK][4];
+  const int64_t row_len = SCORES ? p.ld : 2 * (int64_t)inner;
+  const float* row0 = p.kv + (b * p.kv_bstride + l) * row_len;
+  const int64_t kv_step = p.kv_lstride * row_len;
+  const float* v0 = row0 + (SCORES ? 0 : inner) + h * HDIM + d0;
+  float vv[LK][4];
 #pragma unroll
-  for (int j = 0; j < LK; ++j) {
-    load4(kv0 + j * kv_step, kk[j]);
-    load4(kv0 + j * kv_step + inner, vv[j]);
-  }
-  // ---- the weights: every lane of the group ends up with all of them; with w_j[l] = p_j of level 0, the DIFFERENCE to level 0
-  //      for the others (the third weight follows from p0 + p1 + p2 = 1; how perceiver_out_kernel uses them is said there),
-  //      P[col][head] = 16 pairs: pair j * NLP + lp = (w_j[2 lp], w_j[2 lp + 1]), j = 0, 1, NLP = ceil(Lq / 2); lane i keeps pair i ----
+  for (int j = 0; j < LK; ++j) load4(v0 + j * kv_step, vv[j]);
+  // ---- the weights.  With w_j[l] = p_j of level 0, the DIFFERENCE to level 0 for the others (the third weight follows from
+  //      p0 + p1 + p2 = 1; how perceiver_out_kernel uses them is said there),
+  //      P[col][head] = 16 pairs: pair j * NLP + lp = (w_j[2 lp], w_j[2 lp + 1]), j = 0, 1, NLP = ceil(Lq / 2); lane i writes pair i ----
   constexpr int NLP = (LQ + 1) / 2;
   float mine[2] = {0.f, 0.f};
-  float p00 = 0.f, p10 = 0.f;
-#pragma unroll
-  for (int c = 0; c < LQ; ++c) {
-    float qv[4];
-    load4(p.q + (int64_t)c * inner + h * HDIM + d0, qv);
-    float sc[LK];
-#pragma unroll
-    for (int j = 0; j < LK; ++j)
-      sc[j] = group16_sum(fmaf(qv[0], kk[j][0], fmaf(qv[1], kk[j][1], fmaf(qv[2], kk[j][2], qv[3] * kk[j][3])))) * scale;
+  float* prow = p.P + (col * p.heads + h) * PO_PS;
+  auto weights = [](const float (&sc)[LK], float& w0, float& w1) {
     const float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
     float e[LK];
 #pragma unroll
     for (int j = 0; j < LK; ++j) e[j] = __expf(sc[j] - m);
     const float inv = 1.0f / ((e[0] + e[1]) + e[2]);
-    float w0 = e[0] * inv, w1 = e[1] * inv;
-    if (c == 0) { p00 = w0; p10 = w1; }
-    else { w0 -= p00; w1 -= p10; }
-    if (i16 == c / 2) mine[c & 1] = w0;
-    if (i16 == NLP + c / 2) mine[c & 1] = w1;
+    w0 = e[0] * inv;
+    w1 = e[1] * inv;
+  };
+  if constexpr (SCORES) {
+    auto dpp = [](float x, auto ctrl) {
+      return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    const int lq = i16 < LQ ? i16 : LQ - 1;   // (lanes past the last level repeat it; their weights are zeroed below)
+    float sc[LK];
+#pragma unroll
+    for (int j = 0; j < LK; ++j) sc[j] = row0[j * kv_step + p.s_off + lq * p.heads + h];
+    float w0, w1;
+    weights(sc, w0, w1);
+    const float p00 = dpp(w0, std::integral_constant<int, 0x150>{}), p10 = dpp(w1, std::integral_constant<int, 0x150>{});   // row_newbcast:0
+    if (i16 > 0) { w0 -= p00; w1 -= p10; }
+    if (i16 >= LQ) w0 = w1 = 0.f;
+    const float n0 = dpp(w0, std::integral_constant<int, 0xB1>{}), n1 = dpp(w1, std::integral_constant<int, 0xB1>{});   // lane i ^ 1
+    // lane 2 lp writes pairs lp and NLP + lp; the lanes from 2 NLP on zero the pairs of their own number (all 16 pairs that
+    // perceiver_out_kernel's lanes read are defined)
+    if (i16 >= 2 * NLP) *reinterpret_cast<float2*>(prow + i16 * 2) = make_float2(0.f, 0.f);
+    if ((i16 & 1) == 0 && i16 < 2 * NLP) {
+      *reinterpret_cast<float2*>(prow + (i16 >> 1) * 2) = make_float2(w0, n0);
+      *reinterpret_cast<float2*>(prow + (NLP + (i16 >> 1)) * 2) = make_float2(w1, n1);
+    }
+  } else {
+    // every lane of the group ends up with all the weights (the dot products are reduced across it); lane i keeps pair i
+    float kk[LK][4];
+#pragma unroll
+    for (int j = 0; j < LK; ++j) load4(row0 + h * HDIM + d0 + j * kv_step, kk[j]);
+    float p00 = 0.f, p10 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LQ; ++c) {
+      float qv[4];
+      load4(p.q + (int64_t)c * inner + h * HDIM + d0, qv);
+      float sc[LK];
+#pragma unroll
+      for (int j = 0; j < LK; ++j)
+        sc[j] = group16_sum(fmaf(qv[0], kk[j][0], fmaf(qv[1], kk[j][1], fmaf(qv[2], kk[j][2], qv[3] * kk[j][3])))) * scale;
+      float w0, w1;
+      weights(sc, w0, w1);
+      if (c == 0) { p00 = w0; p10 = w1; }
+      else { w0 -= p00; w1 -= p10; }
+      if (i16 == c / 2) mine[c & 1] = w0;
+      if (i16 == NLP + c / 2) mine[c & 1] = w1;
+    }
+    // (lanes past the last pair write zeros: the 16 pairs perceiver_out_kernel's lanes read are defined everywhere)
+    *reinterpret_cast<float2*>(prow + i16 * 2) = make_float2(mine[0], mine[1]);
   }
-  float* prow = p.P + (col * p.heads + h) * PO_PS;
-  // (lanes past the last pair write zeros: the 16 pairs perceiver_out_kernel's lanes read are defined everywhere)
-  *reinterpret_cast<float2*>(prow + i16 * 2) = make_float2(mine[0], mine[1]);
   // ---- the values as fp16 pairs: lanes 2i, 2i + 1 hold 8 consecutive features between them and trade halves; the even
   //      lane stores the eight high halves, the odd one the remainders (the layout of aurora_hip_split_f16) ----
   const bool odd = (threadIdx.x & 1) != 0;
@@ -496,6 +531,25 @@ extern "C" int aurora_hip_perceiver_out_supported(int Lq, int Lk, int heads, int
   return (Lq == 3 || Lq == 4 || Lq == 13) && Lk == 3 && head_dim == 64 && heads >= 2 && heads % 2 == 0 && N > 0 && N % PO_N == 0;
 }
 
+namespace {
+int launch_probs(const PercProbArgs& p, int Lq, bool scores, void* stream) {
+  const int64_t items = (int64_t)p.B * p.cols_per_b * p.heads * 16;
+  const dim3 grid((unsigned)((items + 255) / 256)), block(256);
+#define AURORA_PROBS(LQ)                                                                                          \
+  do {                                                                                                            \
+    if (scores) hipLaunchKernelGGL((perceiver_probs_kernel<LQ, true>), grid, block, 0, as_stream(stream), p);     \
+    else hipLaunchKernelGGL((perceiver_probs_kernel<LQ, false>), grid, block, 0, as_stream(stream), p);           \
+  } while (0)
+  switch (Lq) {
+    case 3: AURORA_PROBS(3); break;
+    case 4: AURORA_PROBS(4); break;
+    default: AURORA_PROBS(13); break;
+  }
+#undef AURORA_PROBS
+  return check_launch("perceiver_probs");
+}
+}  // namespace
+
 extern "C" int aurora_hip_perceiver_probs(const float* q, const float* kv, float* P, void* Vp, int B, int64_t cols_per_b,
                                           int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads, int head_dim,
                                           const float* guard, float guard_limit, void* stream) {
@@ -504,15 +558,22 @@ extern "C" int aurora_hip_perceiver_probs(const float* q, const float* kv, float
   AURORA_CHECK_ARG(q && kv && P && Vp && B > 0 && cols_per_b > 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)kv % 16) == 0 &&
                        ((uintptr_t)P % 16) == 0 && ((uintptr_t)Vp % 16) == 0,
                    "perceiver_probs: null / unaligned argument");
-  PercProbArgs p{q, kv, P, (char*)Vp, B, cols_per_b, kv_bstride, kv_lstride, heads, guard, guard_limit};
-  const int64_t items = (int64_t)B * cols_per_b * heads * 16;
-  const dim3 grid((unsigned)((items + 255) / 256)), block(256);
-  switch (Lq) {
-    case 3: hipLaunchKernelGGL(perceiver_probs_kernel<3>, grid, block, 0, as_stream(stream), p); break;
-    case 4: hipLaunchKernelGGL(perceiver_probs_kernel<4>, grid, block, 0, as_stream(stream), p); break;
-    default: hipLaunchKernelGGL(perceiver_probs_kernel<13>, grid, block, 0, as_stream(stream), p); break;
-  }
-  return check_launch("perceiver_probs");
+  PercProbArgs p{q, kv, P, (char*)Vp, B, cols_per_b, kv_bstride, kv_lstride, heads, guard, guard_limit, 0, 0};
+  return launch_probs(p, Lq, false, stream);
+}
+
+extern "C" int aurora_hip_perceiver_probs_scores(const float* vs, int64_t ld_vs, int s_off, float* P, void* Vp, int B,
+                                                 int64_t cols_per_b, int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk,
+                                                 int heads, int head_dim, const float* guard, float guard_limit, void* stream) {
+  AURORA_CHECK_ARG(aurora_hip_perceiver_out_supported(Lq, Lk, heads, head_dim, PO_N),
+                   "perceiver_probs_scores: Lq=%d Lk=%d head_dim=%d (built for Lq in {3, 4, 13}, Lk = 3, head_dim 64)", Lq, Lk,
+                   head_dim);
+  AURORA_CHECK_ARG(vs && P && Vp && B > 0 && cols_per_b > 0 && ((uintptr_t)vs % 16) == 0 && ((uintptr_t)P % 16) == 0 &&
+                       ((uintptr_t)Vp % 16) == 0 && ld_vs % 4 == 0 && s_off >= heads * head_dim &&
+                       ld_vs >= (int64_t)s_off + (int64_t)Lq * heads,
+                   "perceiver_probs_scores: a row is [v (heads * head_dim) | ... | scores (Lq * heads) at s_off], ld %% 4 == 0");
+  PercProbArgs p{nullptr, vs, P, (char*)Vp, B, cols_per_b, kv_bstride, kv_lstride, heads, guard, guard_limit, ld_vs, s_off};
+  return launch_probs(p, Lq, true, stream);
 }
 
 extern "C" int aurora_hip_perceiver_out(const void* Vp, const void* W_pairs, int64_t ldw, const float* P, const float* bias,

@@ -45,7 +45,11 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     float* y = (float*)m.arena.take(unit);
     const size_t after_y = m.arena.top;
     float* lat1 = (float*)m.arena.take(unit);   // fp32 values, or their fp16 pairs
-    const size_t kv_bytes = (size_t)ctx_rows * 2 * inner * 4, q_bytes = i > 0 ? (size_t)n_rows * inner * 4 : 0;
+    // First layer, queries known at pack time: the context rows leave `to_kv` as [v | scores with every query] -- no keys
+    // (model.hip:score_weights); else k | v.
+    const bool scores = i == 0 && rs.n_vs > 0 && rs.vs_lq == Lq && ly.ln_k_w == nullptr;
+    const int kv_ld = scores ? rs.n_vs : 2 * inner;
+    const size_t kv_bytes = (size_t)ctx_rows * kv_ld * 4, q_bytes = i > 0 ? (size_t)n_rows * inner * 4 : 0;
     const size_t att_bytes = (size_t)n_rows * inner * 4;
     const bool att_in_y = att_bytes <= unit;   // (inner <= dim in every published model; else behind everything it coexists with)
     const size_t kvq_bytes = ((kv_bytes + 255) & ~size_t(255)) + ((q_bytes + 255) & ~size_t(255));
@@ -85,7 +89,7 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
     };
     // |ctx| <= g_a * word + g_c < F16_SAFE  <=>  word < (F16_SAFE - g_c) / g_a; a context in pairs comes with its own limit
     REQUIRE(!ctx_pairs || ly.to_kv_s, "resampler: a pair-layout context needs pre-split to_kv weights");
-    guarded(ctx, ctx_dim, ly.to_kv, ly.to_kv_s, kv, 2 * inner, ctx_rows, 2 * inner, ctx_dim,
+    guarded(ctx, ctx_dim, scores ? rs.vs_w.f() : ly.to_kv, scores ? rs.vs_ws.p : ly.to_kv_s, kv, kv_ld, ctx_rows, kv_ld, ctx_dim,
             ctx_pairs ? cg->limit_kv : (F16_SAFE - g_c) / g_a, ctx_pairs);
     if (ly.ln_k_w)   // LayerNorm over the K half, in place (perceiver.py:144-147)
       L.layernorm(kv, 2 * inner, ly.ln_k_w, ly.ln_k_b, nullptr, 0, 0, kv, 2 * inner, nullptr, 0, ctx_rows, inner, 1e-5f,
@@ -108,6 +112,9 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
       float* P = (float*)(S + p_off);
       void* Vp = y;
       timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] {
+        if (scores)
+          return aurora_hip_perceiver_probs_scores(kv, kv_ld, inner, P, Vp, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim,
+                                                   ctx_max, lim_out, L.stream);
         return aurora_hip_perceiver_probs(q, kv, P, Vp, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim, ctx_max, lim_out,
                                           L.stream);
       });
@@ -119,12 +126,18 @@ float* resampler(Model& m, Launcher& L, const Resampler& rs, const float* ctx, i
       // Values outside fp16's range (the same word decides, on the device): the plain pair -- attention output in fp32, to_out
       // on three bf16 terms -- runs instead; inside the range both launches retire at once.
       timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] {
+        if (scores)
+          return aurora_hip_perceiver_attention_scores(kv, kv_ld, inner, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads,
+                                                       ly.head_dim, nullptr, 0.f, ctx_max, lim_out, L.stream);
         return aurora_hip_perceiver_attention_unless(q, q_stride, kv, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads,
                                                      ly.head_dim, AURORA_F32, nullptr, 0.f, ctx_max, lim_out, L.stream);
       });
       L.linear(att, inner, ly.to_out, inner, nullptr, o, Dd, n_rows, Dd, inner, AURORA_F32, 0, nullptr, 0, nullptr, 0, 1, ctx_max, lim_out);
     } else {
       timed(m, L.stream, K_PERCEIVER_ATTENTION, 0.0, [&] {
+        if (scores)
+          return aurora_hip_perceiver_attention_scores(kv, kv_ld, inner, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads,
+                                                       ly.head_dim, att_pairs ? ctx_max : nullptr, lim_out, nullptr, 0.f, L.stream);
         return aurora_hip_perceiver_attention_ex(q, q_stride, kv, att, B, cols, kv_bstride, kv_lstride, Lq, Lk, heads, ly.head_dim,
                                                  AURORA_F32, att_pairs ? ctx_max : nullptr, lim_out, L.stream);
       });

@@ -104,6 +104,11 @@ _SIGNATURES = {
     "aurora_hip_perceiver_out_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "aurora_hip_perceiver_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64,
                                            c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
+    "aurora_hip_perceiver_attention_scores": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int64, c_int64,
+                                                      c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_float,
+                                                      c_void_p]),
+    "aurora_hip_perceiver_probs_scores": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int64, c_int64,
+                                                  c_int64, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
     "aurora_hip_perceiver_out": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                          c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
     "aurora_hip_assemble_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -541,6 +546,36 @@ def perceiver_probs(q: torch.Tensor, kv: torch.Tensor, B: int, cols_per_b: int, 
     return P, Vp
 
 
+def perceiver_attention_scores(vs: torch.Tensor, s_off: int, out: torch.Tensor, B: int, cols_per_b: int, kv_bstride: int,
+                               kv_lstride: int, Lq: int, Lk: int, heads: int, head_dim: int, pair_guard=None,
+                               skip_guard=None) -> torch.Tensor:
+    """Perceiver attention from pre-multiplied scores: a row of `vs` is [v | ... | scores (Lq * heads) at s_off]
+    (aurora_hip_perceiver_attention_scores)."""
+    assert vs.is_contiguous() and out.is_contiguous() and vs.dtype == out.dtype == torch.float32
+    word, limit = pair_guard if pair_guard is not None else (None, 0.0)
+    sword, slimit = skip_guard if skip_guard is not None else (None, 0.0)
+    with _Timed("perceiver_attention", 0.0):
+        _check(load().aurora_hip_perceiver_attention_scores(_ptr(vs), vs.shape[1], s_off, _ptr(out), B, cols_per_b, kv_bstride,
+                                                            kv_lstride, Lq, Lk, heads, head_dim, _ptr(word), float(limit),
+                                                            _ptr(sword), float(slimit), _stream()))
+    return out
+
+
+def perceiver_probs_scores(vs: torch.Tensor, s_off: int, B: int, cols_per_b: int, kv_bstride: int, kv_lstride: int,
+                           Lq: int, Lk: int, heads: int, head_dim: int, guard=None):
+    """perceiver_probs from pre-multiplied scores (aurora_hip_perceiver_probs_scores)."""
+    assert vs.is_contiguous() and vs.dtype == torch.float32
+    n_cols, inner = B * cols_per_b, heads * head_dim
+    P = torch.zeros((n_cols, heads, 64), device=vs.device, dtype=torch.float32)
+    Vp = torch.zeros((n_cols * Lk, inner), device=vs.device, dtype=torch.float32)
+    word, limit = guard if guard is not None else (None, 0.0)
+    with _Timed("perceiver_attention", 0.0):
+        _check(load().aurora_hip_perceiver_probs_scores(_ptr(vs), vs.shape[1], s_off, _ptr(P), _ptr(Vp), B, cols_per_b,
+                                                        kv_bstride, kv_lstride, Lq, Lk, heads, head_dim, _ptr(word),
+                                                        float(limit), _stream()))
+    return P, Vp
+
+
 def perceiver_out(Vp: torch.Tensor, w_pairs: torch.Tensor, P: torch.Tensor, out: torch.Tensor, n_cols: int, Lq: int,
                   Lk: int, heads: int, head_dim: int, bias: Optional[torch.Tensor] = None, guard=None) -> torch.Tensor:
     """out[col * Lq + l] = sum_h sum_j P[col, h, l, j] W[:, h] Vp[col * Lk + j, h] (aurora_hip_perceiver_out)."""
@@ -612,7 +647,7 @@ _PS = ctypes.POINTER(ctypes.c_char_p)
 
 class HipTuning(ctypes.Structure):   # aurora_hip_config.tuning: 0 = the library's default
     _fields_ = [("fuse_ln", c_int32), ("band_split_attention", c_int32), ("qkv_planes", c_int32), ("split_k", c_int32),
-                ("perceiver_reassoc", c_int32), ("kv_halo", c_int32), ("reserved", c_int32 * 2)]
+                ("perceiver_reassoc", c_int32), ("score_weights", c_int32), ("reserved", c_int32 * 2)]
 
 
 def tuning_from_env() -> HipTuning:
@@ -624,7 +659,7 @@ def tuning_from_env() -> HipTuning:
         t.fuse_ln = int(e("AURORA_FUSE_LN")) + 1            # 0 / 1 / 2 -> never / fill rule / always
     for field, var in (("band_split_attention", "AURORA_BAND_SPLIT_ATTENTION"), ("qkv_planes", "AURORA_QKV_PLANES"),
                        ("split_k", "AURORA_SPLIT_K"), ("perceiver_reassoc", "AURORA_PERCEIVER_REASSOC"),
-                       ("kv_halo", "AURORA_KV_HALO")):
+                       ("score_weights", "AURORA_SCORE_WEIGHTS")):
         if e(var) is not None:
             setattr(t, field, 2 if int(e(var)) != 0 else 1)
     return t

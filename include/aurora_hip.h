@@ -306,6 +306,19 @@ int aurora_hip_perceiver_out_supported(int Lq, int Lk, int heads, int head_dim, 
 int aurora_hip_perceiver_probs(const float* q, const float* kv, float* P, void* Vp, int B, int64_t cols_per_b,
                                int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads, int head_dim,
                                const float* guard, float guard_limit, void* stream);
+/* The same two from PRE-MULTIPLIED scores.  The queries of a first Perceiver layer are model constants, so
+ * q_l . (W_k x_j) = (W_k^T q_l) . x_j: the key half of `to_kv` (perceiver.py:141-143) shrinks from heads * head_dim columns to
+ * Lq * heads rows made at pack time (scaled by 1 / sqrt(head_dim)).  A context row of `vs` (ld_vs floats apart, row index as kv
+ * above) holds [v (heads * head_dim) | ... | score of (query l, head h) at s_off + l * heads + h].  fp32 only.
+ * _attention_scores: out / pair_guard / skip_guard as aurora_hip_perceiver_attention_unless.
+ * _probs_scores: P / Vp / guard as aurora_hip_perceiver_probs. */
+int aurora_hip_perceiver_attention_scores(const float* vs, int64_t ld_vs, int s_off, void* out, int B, int64_t cols_per_b,
+                                          int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads, int head_dim,
+                                          const float* pair_guard, float pair_limit, const float* skip_guard, float skip_limit,
+                                          void* stream);
+int aurora_hip_perceiver_probs_scores(const float* vs, int64_t ld_vs, int s_off, float* P, void* Vp, int B, int64_t cols_per_b,
+                                      int64_t kv_bstride, int64_t kv_lstride, int Lq, int Lk, int heads, int head_dim,
+                                      const float* guard, float guard_limit, void* stream);
 int aurora_hip_perceiver_out(const void* Vp, const void* W_pairs, int64_t ldw, const float* P, const float* bias,
                              float* out, int64_t ldo, int64_t n_cols, int Lq, int Lk, int heads, int head_dim, int N,
                              const float* guard, float guard_limit, void* stream);
@@ -442,8 +455,8 @@ typedef struct aurora_hip_config {   /* Aurora.__init__ keywords, aurora/model/a
     int32_t split_k;               /* few-tile / long-K bf16 linears split along K (default on; off: a band's bf16 arithmetic is the
                                       un-sharded step's bit for bit whatever the CU count) */
     int32_t perceiver_reassoc;     /* decoder de-aggregation re-associated (aurora_hip_perceiver_out; default on) */
-    int32_t kv_halo;               /* sharded steps: neighbours exchange k | v of their boundary rows instead of re-projecting each
-                                      other's input rows (default on) */
+    int32_t score_weights;         /* first Perceiver layers: to_kv's key half replaced by the Lq * heads rows W_k^T q_l (the queries
+                                      are model constants), attention from those scores (default on; off: k | v, then q . k) */
     int32_t reserved[2];
   } tuning;
 } aurora_hip_config;

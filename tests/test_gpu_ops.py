@@ -762,6 +762,73 @@ def test_perceiver_out_reassociated_equals_attention_then_to_out(Lq, heads, N, c
     assert relerr(out, ref) < 3e-6
 
 
+def _score_rows(q, w_kv, ctx, Lq, heads, hd):
+    """fp64: the context rows as [v | scaled scores with every query | zero padding to a multiple of 4] -- what `to_kv` leaves
+    when its key half is replaced by the rows W_k^T q_l / sqrt(head_dim) (model.hip:score_weights)."""
+    inner = heads * hd
+    w_s = torch.einsum("lhd,hdc->lhc", q.reshape(Lq, heads, hd), w_kv[:inner].reshape(heads, hd, -1)) / hd ** 0.5
+    w_vs = torch.cat([w_kv[inner:], w_s.reshape(Lq * heads, -1)], dim=0)
+    return ctx @ w_vs.T   # (rows, inner + Lq * heads)
+
+
+# (the encoder's level aggregation: 3 latent queries over 13 levels; the decoder's de-aggregation: 13 level queries over 3
+#  latents; a generic shape; head_dim 32)
+@pytest.mark.parametrize("Lq,Lk,heads,hd,cols,B", [(3, 13, 16, 64, 70, 1), (13, 3, 16, 64, 41, 2), (5, 7, 4, 64, 33, 1), (4, 6, 8, 32, 29, 2)])
+@pytest.mark.parametrize("pairs", [False, True])
+def test_perceiver_attention_from_scores_equals_attention_on_keys(Lq, Lk, heads, hd, cols, B, pairs):
+    """perceiver.py:141-152 with q . (W_k x) re-associated as (W_k^T q) . x: same softmax weights, same values."""
+    L = lib()
+    inner, D = heads * hd, 96
+    q = rnd(Lq, inner, seed=1)
+    w_kv = rnd(2 * inner, D, seed=2, scale=D ** -0.5)
+    ctx = rnd(B * Lk * cols, D, seed=3)   # rows (b, j, col)
+    kv = ctx @ w_kv.T
+    vs = _score_rows(q, w_kv, ctx, Lq, heads, hd)
+    ld = (vs.shape[1] + 7) // 8 * 8
+    vs_dev = torch.zeros(vs.shape[0], ld, device=DEV)
+    vs_dev[:, :vs.shape[1]] = vs.float().to(DEV)
+    word = torch.tensor([1.0], device=DEV)
+    guard = (word, 2.0) if pairs else None
+    want = torch.full((B * cols * Lq, inner), float("nan"), device=DEV)
+    L.perceiver_attention(q.float().to(DEV), 0, kv.float().to(DEV).contiguous(), want, B, cols, Lk * cols, cols, Lq, Lk, heads, hd,
+                          pair_guard=guard)
+    got = torch.full((B * cols * Lq, inner), float("nan"), device=DEV)
+    L.perceiver_attention_scores(vs_dev, inner, got, B, cols, Lk * cols, cols, Lq, Lk, heads, hd, pair_guard=guard)
+    torch.cuda.synchronize()
+    if pairs:   # both wrote fp16 pairs: compare the values they stand for
+        want, got = sum(_unsplit(want)), sum(_unsplit(got))
+    kvr = kv.reshape(B, Lk, cols, 2, heads, hd).permute(3, 0, 2, 4, 1, 5)
+    qq = q.reshape(Lq, heads, hd).permute(1, 0, 2)[None, None].expand(B, cols, -1, -1, -1)
+    ref = F.scaled_dot_product_attention(qq, kvr[0], kvr[1]).permute(0, 1, 3, 2, 4).reshape(B * cols * Lq, inner)
+    assert relerr(got, ref) < 2e-6 and relerr(want, ref) < 2e-6
+    # a skip guard that holds retires the launch
+    L.perceiver_attention_scores(vs_dev, inner, got.fill_(-7.0), B, cols, Lk * cols, cols, Lq, Lk, heads, hd, skip_guard=(word, 2.0))
+    torch.cuda.synchronize()
+    assert bool((got == -7.0).all())
+
+
+@pytest.mark.parametrize("Lq,heads,cols,B", [(13, 16, 53, 1), (4, 2, 37, 2), (3, 4, 20, 1)])
+def test_perceiver_probs_from_scores_equal_probs_on_keys(Lq, heads, cols, B):
+    L = lib()
+    Lk, hd, D = 3, 64, 128
+    inner = heads * hd
+    q = rnd(Lq, inner, seed=1)
+    w_kv = rnd(2 * inner, D, seed=2, scale=D ** -0.5)
+    ctx = rnd(B * Lk * cols, D, seed=3)
+    kv = (ctx @ w_kv.T).float().to(DEV).contiguous()
+    vs = _score_rows(q, w_kv, ctx, Lq, heads, hd)
+    ld = (vs.shape[1] + 255) // 256 * 256   # (zero columns behind the scores, as the padded weight rows leave them)
+    vs_dev = torch.zeros(vs.shape[0], ld, device=DEV)
+    vs_dev[:, :vs.shape[1]] = vs.float().to(DEV)
+    P0, V0 = L.perceiver_probs(q.float().to(DEV), kv, B, cols, Lk * cols, cols, Lq, Lk, heads, hd)
+    P1, V1 = L.perceiver_probs_scores(vs_dev, inner, B, cols, Lk * cols, cols, Lq, Lk, heads, hd)
+    torch.cuda.synchronize()
+    assert torch.equal(V0, V1)   # the same value rows, split the same way
+    assert (P0 - P1).abs().max().item() < 2e-6 and bool((P1[:, :, 32:] == 0).all())
+    nlp = (Lq + 1) // 2
+    assert bool((P1[:, :, 4 * nlp:32] == 0).all())
+
+
 @pytest.mark.parametrize("holds", [True, False])
 def test_perceiver_out_pair_and_plain_pair_follow_the_guard(holds):
     """The device word picks exactly one of {probs + out, attention + (three-term) to_out}; the other pair retires."""

@@ -143,6 +143,23 @@ def test_decoder_reassociation_equals_attention_then_to_out_at_model_level(monke
     assert 0 < worst < 2e-6   # (not the same launches -- and not further apart than fp32 summation orders are)
 
 
+def test_scores_from_packed_query_rows_equal_key_projection_at_model_level(monkeypatch):
+    """First Perceiver layers (encoder level aggregation, decoder de-aggregation): `to_kv` with its key half replaced by the
+    Lq x heads rows W_k^T q / sqrt(64) (csrc/model.hip:score_weights) and attention from those scores, against keys + q . k in
+    the same fp32 model at the production widths -- the same function re-associated; fp32 round-off apart."""
+    outs = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("AURORA_SCORE_WEIGHTS", on)
+        model = _seeded_model(aurora_amd.AuroraPretrained, autocast=False)
+        batch = _inputs(model.config, 181, 360, LEVELS13)
+        outs[on] = _engine(model, batch)
+        del model
+        torch.cuda.empty_cache()
+    worst = max(helpers.mean_rel_err(outs["1"][k], outs["0"][k]) for k in outs["0"])
+    print(f"scores from packed query rows vs key projection: worst mean-rel {worst:.3e}")
+    assert 0 < worst < 2e-6
+
+
 def test_pretrained_quarter_grid_matches_oracle():
     """AuroraPretrained() on 361 x 720 = a quarter of the 0.25-degree tokens (token grid (4, 90, 180); stages (45, 90) and
     (23, 45) padded): M = 64,800 / 16,200 / 4,140 rows per stage, so the M-dependent dispatch of the headline step is
