@@ -327,6 +327,12 @@ def main() -> None:
             control = dist.new_group(backend="gloo")
         except Exception as e:  # noqa: BLE001  -- agreement then runs over the main group, as it did before
             log(f"no gloo control group ({e!r}); using the main process group")
+        # every rank must use the SAME group: if the control group failed anywhere, nobody uses it (agreed over the main group,
+        # which at this point has just been initialised and has carried nothing yet)
+        have = [None] * world
+        dist.all_gather_object(have, control is not None)
+        if not all(have):
+            control = None
     bands_error = None
 
     mode = os.environ.get("AURORA_BENCH_MODE", "bands") if distributed else "single"
@@ -376,9 +382,14 @@ def main() -> None:
         batch = synthetic_batch(model.config, GH, GW, 1 + (rank if mode == "replicas" else 0), device)
     log("batch on device")
 
+    # After a failed halo self-test RCCL's state is unknown: from there on the ranks meet over the host-side group only
+    # (barriers, the elapsed-time reduction), so that the replica fall-back leaves its record whatever the fabric does.
+    host_sync = bands_error is not None and control is not None
+
     def barrier():
         if distributed:
-            dist.barrier()
+            torch.cuda.synchronize()
+            dist.barrier(group=control if host_sync else None)
         torch.cuda.synchronize()
 
     with torch.inference_mode():
@@ -429,8 +440,9 @@ def main() -> None:
     assert torch.isfinite(pred.surf_vars["2t"]).all()
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        on_host = host_sync or dist.get_backend() != "nccl"
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if on_host else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=control if host_sync else None)
         elapsed = t.item()
 
     failed = False
@@ -537,7 +549,7 @@ def main() -> None:
                               f"(tools/time_reference.py, profiles/{ref.name})"}
         print(json.dumps(out), flush=True)
     if distributed:
-        dist.barrier()
+        dist.barrier(group=control if host_sync else None)
         dist.destroy_process_group()
     if failed:
         log("FULL-GRID PARITY VIOLATED (see parity_full_grid in the JSON line)")

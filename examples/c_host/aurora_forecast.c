@@ -6,7 +6,8 @@
  * file (aurora_hip_save_packed; no pickle, no checkpoint adapters on this side).
  *
  *   aurora_forecast <case-dir>
- *   aurora_forecast <case-dir> --rank R --world N --nccl-id FILE [--device D]      (built with -DAURORA_WITH_RCCL)
+ *   aurora_forecast <case-dir> --rank R --world N --nccl-id FILE [--run-nonce N] [--device D]      (built with -DAURORA_WITH_RCCL;
+ *                   N: the same non-zero number for every rank of ONE run -- a stale bootstrap file is then never taken for it)
  *
  * The second form runs ONE latitude band of the forecast: N processes, one per GPU, started by any
  * launcher (a shell loop will do); rank 0 writes RCCL's unique id to FILE, the others read it; the halo rows of the
@@ -182,6 +183,7 @@ static void push_history(float* hist, const float* pred, int B, int T, size_t pl
 int main(int argc, char** argv) {
   int rank = -1, world = 1, device = -1;
   const char* id_file = NULL;
+  unsigned long long run_nonce = 0;
   int bad = argc < 2;
   for (int i = 2; i < argc && !bad; i += 2) {
     if (i + 1 >= argc) bad = 1;
@@ -189,15 +191,17 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--world")) world = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--device")) device = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--nccl-id")) id_file = argv[i + 1];
+    else if (!strcmp(argv[i], "--run-nonce")) run_nonce = strtoull(argv[i + 1], NULL, 10);
     else bad = 1;
   }
   if (world > 1 && (rank < 0 || rank >= world || !id_file)) bad = 1;
   if (bad) {
-    fprintf(stderr, "usage: aurora_forecast <case-dir> [--rank R --world N --nccl-id FILE [--device D]]   (library ABI version %d)\n",
+    fprintf(stderr, "usage: aurora_forecast <case-dir> [--rank R --world N --nccl-id FILE [--run-nonce N] [--device D]]   (library ABI version %d)\n",
             aurora_hip_version());
     return 2;
   }
 #ifndef AURORA_WITH_RCCL
+  (void)run_nonce;
   if (world > 1) die("band mode", "this binary was built without -DAURORA_WITH_RCCL");
 #endif
   if (world <= 1) rank = -1;
@@ -222,7 +226,7 @@ int main(int argc, char** argv) {
 #ifdef AURORA_WITH_RCCL
   static rccl_transport transport;
   if (world > 1) {   /* call order of include/aurora_hip.h: set_band, precompute with the FULL grid, band_rows, staging */
-    if (rccl_transport_init(&transport, rank, world, id_file, 120.0) != 0) die("RCCL", transport.error);
+    if (rccl_transport_init(&transport, rank, world, id_file, run_nonce, 120.0) != 0) die("RCCL", transport.error);
     aurora_hip_band band;
     band.rank = rank, band.world = world;
     band.post = rccl_transport_post, band.wait = rccl_transport_wait, band.user = &transport;

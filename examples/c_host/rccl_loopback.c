@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
   const int64_t n = 1 << 20;
   CHECK_HIP(hipSetDevice(0));
   rccl_transport t;
-  if (rccl_transport_init(&t, 0, 1, id_file, 30.0) != 0) {
+  if (rccl_transport_init(&t, 0, 1, id_file, 0, 30.0) != 0) {
     fprintf(stderr, "RCCL-UNAVAILABLE %s\n", t.error);
     return 77;
   }

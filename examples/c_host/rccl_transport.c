@@ -30,39 +30,51 @@ static double now_s(void) {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-int rccl_transport_init(rccl_transport* t, int rank, int world, const char* id_file, double timeout_s) {
+/* what the bootstrap file holds */
+typedef struct { unsigned long long magic, nonce; ncclUniqueId id; } id_record;
+#define ID_MAGIC 0x4155524f52414944ull   /* "AURORAID" */
+
+int rccl_transport_init(rccl_transport* t, int rank, int world, const char* id_file, unsigned long long run_nonce,
+                        double timeout_s) {
   memset(t, 0, sizeof *t);
   t->rank = rank, t->world = world;
   if (world < 1 || rank < 0 || rank >= world) T_FAIL(t, "bad rank %d of %d", rank, world);   /* (world 1: rccl_loopback.c) */
-  ncclUniqueId id;
+  if (!id_file || strlen(id_file) + 5 > sizeof t->id_file) T_FAIL(t, "bootstrap path missing or longer than %zu bytes", sizeof t->id_file - 5);
+  id_record rec;
+  memset(&rec, 0, sizeof rec);
   if (rank == 0) {
-    T_NCCL(t, ncclGetUniqueId(&id));
-    char tmp[4096];
+    rec.magic = ID_MAGIC, rec.nonce = run_nonce;
+    T_NCCL(t, ncclGetUniqueId(&rec.id));
+    char tmp[sizeof t->id_file + 8];
     snprintf(tmp, sizeof tmp, "%s.tmp", id_file);
     FILE* f = fopen(tmp, "wb");
     if (!f) T_FAIL(t, "cannot write %.200s", tmp);
-    const size_t n = fwrite(&id, sizeof id, 1, f);
+    const size_t n = fwrite(&rec, sizeof rec, 1, f);
     if (fclose(f) != 0 || n != 1) T_FAIL(t, "cannot write %.200s", tmp);
     if (rename(tmp, id_file) != 0) T_FAIL(t, "cannot rename %.200s", tmp);   /* (replaces a stale file atomically) */
     snprintf(t->id_file, sizeof t->id_file, "%s", id_file);                  /* removed again by rccl_transport_destroy */
   } else {
-    /* A file left behind by a run that crashed must not be taken for this run's: only a file written within the last
-     * `timeout_s` seconds counts (rank 0 of THIS run renames its file into place within that window or this rank gives up
-     * anyway), and rank 0 removes its file when it is done.  Launchers should still pass a path that is new per run. */
+    /* A file left behind by a run that crashed must not be taken for this run's.  With a launcher-provided nonce: only a
+     * record that carries it counts (whatever its age, whatever the clocks say).  Without one: only a file written within
+     * the last `timeout_s` seconds (rank 0 of THIS run renames its file into place within that window or this rank gives up
+     * anyway). */
     const double t0 = now_s();
     for (;;) {
       struct stat st;
-      FILE* f = stat(id_file, &st) == 0 && difftime(time(NULL), st.st_mtime) <= timeout_s + 2.0 ? fopen(id_file, "rb") : NULL;
+      const int fresh = run_nonce != 0 || (stat(id_file, &st) == 0 && difftime(time(NULL), st.st_mtime) <= timeout_s + 2.0);
+      FILE* f = fresh ? fopen(id_file, "rb") : NULL;
       if (f) {
-        const size_t n = fread(&id, sizeof id, 1, f);
+        const size_t n = fread(&rec, sizeof rec, 1, f);
         fclose(f);
-        if (n == 1) break;
+        if (n == 1 && rec.magic == ID_MAGIC && rec.nonce == run_nonce) break;
       }
-      if (now_s() - t0 > timeout_s) T_FAIL(t, "no ncclUniqueId in %.180s after %.0f s", id_file, timeout_s);
+      if (now_s() - t0 > timeout_s)
+        T_FAIL(t, "no ncclUniqueId of run %llu in %.160s after %.0f s", run_nonce, id_file, timeout_s);
       struct timespec nap = {0, 20 * 1000 * 1000};
       nanosleep(&nap, NULL);
     }
   }
+  const ncclUniqueId id = rec.id;
   T_NCCL(t, ncclCommInitRank(&t->comm, world, id, rank));
   T_HIP(t, hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
   T_HIP(t, hipEventCreateWithFlags(&t->ready, hipEventDisableTiming));

@@ -35,11 +35,15 @@ typedef struct rccl_transport {
   char error[256];           /* last failure, for the host's message (the callbacks only return -1) */
 } rccl_transport;
 
-/* Bootstrap without MPI: rank 0 creates the ncclUniqueId and writes it to `id_file` (atomically: temp file + rename), the
- * other ranks poll for a file that is at most timeout_s seconds old (a file left by a crashed run is ignored; rank 0 removes
- * its file in rccl_transport_destroy; pass a path that is new per run all the same).  Then ncclCommInitRank.  The caller
- * has selected its device. */
-int rccl_transport_init(rccl_transport* t, int rank, int world, const char* id_file, double timeout_s);
+/* Bootstrap without MPI: rank 0 creates the ncclUniqueId and writes {magic, run_nonce, id} to `id_file` (atomically: temp
+ * file + rename), the other ranks poll for a file that carries THEIR run_nonce -- the launcher hands every rank of one run
+ * the same non-zero number (a time stamp, a job id), so a file left behind by a crashed run, however recent, is never taken
+ * for this run's.  run_nonce 0: no launcher-provided number; a file then counts if it is at most timeout_s seconds old (a
+ * relaunch within that window can still meet the old file: pass a nonce, or a path that is new per run).  Rank 0 removes
+ * its file in rccl_transport_destroy.  Then ncclCommInitRank.  The caller has selected its device.  `id_file` must fit
+ * rccl_transport.id_file. */
+int rccl_transport_init(rccl_transport* t, int rank, int world, const char* id_file, unsigned long long run_nonce,
+                        double timeout_s);
 /* Allocates the two staging buffers (call after aurora_hip_precompute: aurora_hip_band_staging_bytes is known then). */
 int rccl_transport_allocate(rccl_transport* t, int64_t staging_bytes);
 /* Every rank sends a rank-stamped pattern of `bytes` to its neighbours and checks what it received: run once before the
