@@ -38,6 +38,10 @@
 
 #include "common.h"
 
+#ifndef F32PP_PARTS   // passes of the two-term fp32 kernel's whole-row epilogue (1, 2 or 4): see linear_kernel_f32pp
+#define F32PP_PARTS 4
+#endif
+
 namespace aurora {
 
 namespace {
@@ -421,7 +425,7 @@ __device__ __forceinline__ void epilogue_256(const LinearArgs& p, f32x4 (&acc)[4
 // its stores and 16.9 us without) -- as long as half the tile's MFMA time.  The ring is dead after the main
 // loop, so each wave borrows 16 KiB of it; LDS rows are XOR-swizzled (piece ^ (row & 7)): conflict-free for the
 // b128 writes (8 rows per lane group) and reads (4 rows x 4 pieces per lane group).
-template <int PARTS>   // 1: a wave's 128 x 64 results in one pass (16 KiB of the dead ring); 2: two passes of 64 rows (8 KiB)
+template <int PARTS>   // 1: a wave's 128 x 64 results in one pass (16 KiB of the dead ring); 2 / 4: passes of 64 / 32 rows (8 / 4 KiB)
 __device__ __forceinline__ void epilogue_256_bf16_coalesced(const LinearArgs& p, f32x4 (&acc)[4][8], int64_t m0,
                                                             int n0, int wm, int wn, int wave, int lane, char* smem) {
   const int i16 = lane & 15, g = lane >> 4;
@@ -893,7 +897,12 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearA
     }
   }
   if (p.C2 == nullptr && p.res == nullptr && p.vec_store) {   // (uniform)
-    epilogue_256_bf16_coalesced<1>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+    // In parts (64 / 32 rows of the wave's 128 at a time): the stores of one part are in flight while the next part's bias,
+    // activation and packing run on the VALU -- in one pass the GELU of a stage-0 fc1 tile (11 VALU instructions per two
+    // values, 9 K cycles per SIMD) ran with no memory operation in flight.  In the step: 129.7 -> 128.2 ms
+    // (profiles/r06_ab_epilogue_parts.log); the same values either way.
+    if (p.act == AURORA_ACT_GELU) epilogue_256_bf16_coalesced<4>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+    else epilogue_256_bf16_coalesced<2>(p, acc, m0, n0, wm, wn, wave, lane, smem);
     return;
   }
   epilogue_256<bf16_t>(p, acc, m0, n0, wm, wn, i16, g);
@@ -1304,9 +1313,15 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
     // layout keeps a wave's 64 features in 256 contiguous bytes too: two groups of 32 high halves + 32 remainders),
     // 16-byte pieces XOR-swizzled by row & 7.
     // (both halves are past their last LDS read: the barrier above is the late half's last in-loop one)
+    // In F32PP_PARTS parts (32 / 16 of the wave's 64 rows at a time): a part's stores are in flight while the next part's
+    // scaling, activation and splitting run on the VALU (as epilogue_256_bf16_coalesced; profiles/r06_ab_epilogue_parts.log).
     char* mine = smem + wave * 16384;
+    const int rr = lane >> 4, cc = lane & 15;
+    float* cbase = reinterpret_cast<float*>(p.C) + n0 + wn * 64 + cc * 4;
 #pragma unroll
-    for (int fm = 0; fm < 4; ++fm) {
+    for (int part = 0; part < F32PP_PARTS; ++part) {
+#pragma unroll
+    for (int fm = part * (4 / F32PP_PARTS); fm < (part + 1) * (4 / F32PP_PARTS); ++fm) {
       float v[16];
 #pragma unroll
       for (int fn = 0; fn < 4; ++fn) {
@@ -1344,14 +1359,13 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
           *reinterpret_cast<f32x4*>(lrow + (((4 * g + q) ^ sw) << 4)) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
       }
     }
-    const int rr = lane >> 4, cc = lane & 15;
-    float* cbase = reinterpret_cast<float*>(p.C) + n0 + wn * 64 + cc * 4;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
+    for (int it = part * (16 / F32PP_PARTS); it < (part + 1) * (16 / F32PP_PARTS); ++it) {
       const int row = it * 4 + rr;
       const f32x4 d = *reinterpret_cast<const f32x4*>(mine + row * 256 + ((cc ^ (row & 7)) << 4));
       const int64_t m = m0 + wm * 64 + row;
       if (m < p.M) *reinterpret_cast<f32x4*>(cbase + m * p.ldc) = d;
+    }
     }
     return;
   }
