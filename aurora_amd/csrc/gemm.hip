@@ -427,13 +427,16 @@ __device__ __forceinline__ void epilogue_256(const LinearArgs& p, f32x4 (&acc)[4
 // b128 writes (8 rows per lane group) and reads (4 rows x 4 pieces per lane group).
 template <int PARTS>   // 1: a wave's 128 x 64 results in one pass (16 KiB of the dead ring); 2 / 4: passes of 64 / 32 rows (8 / 4 KiB)
 __device__ __forceinline__ void epilogue_256_bf16_coalesced(const LinearArgs& p, f32x4 (&acc)[4][8], int64_t m0,
-                                                            int n0, int wm, int wn, int wave, int lane, char* smem) {
+                                                            int n0, int wm, int wn, int wave, int lane, char* smem,
+                                                            const float (*bias_pre)[16] = nullptr) {
   const int i16 = lane & 15, g = lane >> 4;
   char* mine = smem + wave * (16384 / PARTS);
   const int nbase = n0 + wn * 64 + 16 * g;
+  // (`bias_pre`: the lane's 16 bias values, requested by the caller before its main loop -- requested here, the first use
+  //  waits out an L2 round trip with nothing else in flight)
   float bias_v[16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
+  for (int t = 0; t < 16; ++t) bias_v[t] = bias_pre ? (*bias_pre)[t] : (p.bias ? p.bias[nbase + t] : 0.f);
   const int rr = lane >> 3, cc = lane & 7;
   // (head planes: the wave's 64 columns are q, k or v of ONE head: 128-byte pieces of its plane's 384-byte rows)
   bf16_t* cbase = out_piece<bf16_t>(p, 0, n0 + wn * 64) + cc * 8;
@@ -690,7 +693,9 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
   if constexpr (sizeof(T) == 2) {
     if (p.C2 == nullptr && p.res == nullptr && p.vec_store) {   // (uniform)
       __syncthreads();   // every wave is done with the ring
-      epilogue_256_bf16_coalesced<1>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+      // (in parts, as in linear_kernel_256pp below)
+      if (p.act == AURORA_ACT_GELU) epilogue_256_bf16_coalesced<4>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+      else epilogue_256_bf16_coalesced<2>(p, acc, m0, n0, wm, wn, wave, lane, smem);
       return;
     }
   } else if constexpr (WN == 4) {
@@ -811,6 +816,16 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearA
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // The lane's 16 bias values, for the epilogue: requested NOW, in front of (and so older than) every piece the counted waits
+  // below leave in flight; 16 registers the main loop does not need (201 of 256 before).  In the step 127.6 -> 127.3 ms
+  // (profiles/r06_ab_epilogue_parts.log).
+  float bias_pre[16];
+  {
+    const int nb16 = n0 + wn * 64 + 16 * g;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) bias_pre[t] = p.bias ? p.bias[nb16 + t] : 0.f;   // (N is a multiple of the tile width here)
+  }
+  asm volatile("" ::: "memory");
   stage(0);
   stage(1);
   stage(2);
@@ -901,8 +916,8 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearA
     // activation and packing run on the VALU -- in one pass the GELU of a stage-0 fc1 tile (11 VALU instructions per two
     // values, 9 K cycles per SIMD) ran with no memory operation in flight.  In the step: 129.7 -> 128.2 ms
     // (profiles/r06_ab_epilogue_parts.log); the same values either way.
-    if (p.act == AURORA_ACT_GELU) epilogue_256_bf16_coalesced<4>(p, acc, m0, n0, wm, wn, wave, lane, smem);
-    else epilogue_256_bf16_coalesced<2>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+    if (p.act == AURORA_ACT_GELU) epilogue_256_bf16_coalesced<4>(p, acc, m0, n0, wm, wn, wave, lane, smem, &bias_pre);
+    else epilogue_256_bf16_coalesced<2>(p, acc, m0, n0, wm, wn, wave, lane, smem, &bias_pre);
     return;
   }
   epilogue_256<bf16_t>(p, acc, m0, n0, wm, wn, i16, g);
@@ -1300,7 +1315,7 @@ __global__ __launch_bounds__(VTHREADS, 2) void linear_kernel_f32pp(const LinearA
 
   // ---- epilogue: lane owns row m (per fm) x 16 consecutive features; undo the 2^6 weight scale (exact) ----
   const int nbase = n0 + wn * 64 + 16 * g;
-  float bias_v[16];
+  float bias_v[16];   // (requested before the main loop instead, as in linear_kernel_256pp: measured, no gain here -- the tiles are long)
 #pragma unroll
   for (int t = 0; t < 16; ++t) bias_v[t] = p.bias ? p.bias[nbase + t] : 0.f;
   const bool vec = p.vec_store != 0;
