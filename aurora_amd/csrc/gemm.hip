@@ -38,12 +38,6 @@
 
 #include "common.h"
 
-#ifndef PP_GELU_PARTS   // passes of the bf16 kernels' whole-row epilogue with / without GELU (1, 2, 4 or 8): see linear_kernel_256pp
-#define PP_GELU_PARTS 4
-#endif
-#ifndef PP_PLAIN_PARTS
-#define PP_PLAIN_PARTS 2
-#endif
 #ifndef F32PP_PARTS   // passes of the two-term fp32 kernel's whole-row epilogue (1, 2 or 4): see linear_kernel_f32pp
 #define F32PP_PARTS 4
 #endif
@@ -700,8 +694,8 @@ __global__ __launch_bounds__(128 * WN, 2) void linear_kernel_256(const LinearArg
     if (p.C2 == nullptr && p.res == nullptr && p.vec_store) {   // (uniform)
       __syncthreads();   // every wave is done with the ring
       // (in parts, as in linear_kernel_256pp below)
-      if (p.act == AURORA_ACT_GELU) epilogue_256_bf16_coalesced<PP_GELU_PARTS>(p, acc, m0, n0, wm, wn, wave, lane, smem);
-      else epilogue_256_bf16_coalesced<PP_PLAIN_PARTS>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+      if (p.act == AURORA_ACT_GELU) epilogue_256_bf16_coalesced<4>(p, acc, m0, n0, wm, wn, wave, lane, smem);
+      else epilogue_256_bf16_coalesced<2>(p, acc, m0, n0, wm, wn, wave, lane, smem);
       return;
     }
   } else if constexpr (WN == 4) {
@@ -922,8 +916,8 @@ __global__ __launch_bounds__(THREADS2, 2) void linear_kernel_256pp(const LinearA
     // activation and packing run on the VALU -- in one pass the GELU of a stage-0 fc1 tile (11 VALU instructions per two
     // values, 9 K cycles per SIMD) ran with no memory operation in flight.  In the step: 129.7 -> 128.2 ms
     // (profiles/r06_ab_epilogue_parts.log); the same values either way.
-    if (p.act == AURORA_ACT_GELU) epilogue_256_bf16_coalesced<PP_GELU_PARTS>(p, acc, m0, n0, wm, wn, wave, lane, smem, &bias_pre);
-    else epilogue_256_bf16_coalesced<PP_PLAIN_PARTS>(p, acc, m0, n0, wm, wn, wave, lane, smem, &bias_pre);
+    if (p.act == AURORA_ACT_GELU) epilogue_256_bf16_coalesced<4>(p, acc, m0, n0, wm, wn, wave, lane, smem, &bias_pre);
+    else epilogue_256_bf16_coalesced<2>(p, acc, m0, n0, wm, wn, wave, lane, smem, &bias_pre);
     return;
   }
   epilogue_256<bf16_t>(p, acc, m0, n0, wm, wn, i16, g);
