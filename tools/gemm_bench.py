@@ -38,6 +38,9 @@ if len(sys.argv) > 2:  # restrict to the named shapes
 PRE = os.environ.get("GEMM_BENCH_PRESPLIT", "")
 FLAGS = (lib.F32_W_SPLIT if "w" in PRE else 0) | (lib.F32_A_SPLIT if "a" in PRE else 0) | (lib.F32_C_SPLIT if "c" in PRE else 0)
 ACT = int(os.environ.get("GEMM_BENCH_ACT", "0"))   # 1 = GELU epilogue
+# GEMM_BENCH_SECONDS = s: every shape runs back to back for s seconds before (and as) it is timed -- the socket then sits at its power
+# cap and the clock the cap allows (profiles/r06_clocks_under_load.log); the default five repetitions on a cool chip flatter every kernel
+SUSTAIN = float(os.environ.get("GEMM_BENCH_SECONDS", "0"))
 VENDOR = bool(os.environ.get("GEMM_BENCH_VENDOR"))   # also time torch's own linear (hipBLASLt / rocBLAS) as a yardstick
 torch.backends.cuda.matmul.allow_tf32 = False
 tot_ms = tot_fl = ven_ms = 0.0
@@ -59,6 +62,13 @@ for name, M, N, K, wt in SHAPES:
     torch.cuda.synchronize()
     reps = 5
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if SUSTAIN > 0:   # calibrate, then one timed run of ~SUSTAIN seconds
+        e0.record()
+        for _ in range(20):
+            lib.linear(a, w, b, out, act=ACT, presplit=FLAGS)
+        e1.record()
+        torch.cuda.synchronize()
+        reps = max(20, int(SUSTAIN * 1e3 / (e0.elapsed_time(e1) / 20)))
     e0.record()
     for _ in range(reps):
         lib.linear(a, w, b, out, act=ACT, presplit=FLAGS)
@@ -83,7 +93,7 @@ for name, M, N, K, wt in SHAPES:
             act(torch.nn.functional.linear(a, w, bt))
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(reps):
+        for _ in range(reps):   # (the same number of repetitions as ours: sustained when GEMM_BENCH_SECONDS is set)
             act(torch.nn.functional.linear(a, w, bt))
         e1.record()
         torch.cuda.synchronize()
